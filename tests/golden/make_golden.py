@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""
+Generate the golden vectors in tests/golden/*.npz by RUNNING THE REFERENCE ITSELF
+(pandekan/tomography_alignment at /root/reference, read-only):
+
+  * the reference python packages `utilities`, `recon` imported from /root/reference,
+  * its two f2py modules (`src.ray_wt_grad`, `src.vox_wt_grad`) and the matrix-free float32
+    Fortran (forward_project_, back_project_, compute_gradient_) compiled from the sources where
+    they lie by oracle/build_ref.sh into oracle/_ref/ (git-ignored).
+
+Only DATA (inputs + expected outputs) is written.  Run in the authoring container:
+    oracle/build_ref.sh && python tests/golden/make_golden.py
+Two import shims (no reference edits): numpy>=2 removed `np.lib.index_tricks`
+(utilities/generate_phantom.py:173) and scipy moved `scipy.optimize.linesearch`
+(utilities/alignment_functions.py:4).
+"""
+import ctypes
+import os
+import sys
+import types
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("REF", "/root/reference")
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))   # `src` resolves to the built f2py modules
+
+import numpy as np  # noqa: E402
+import numpy.lib._index_tricks_impl as _it  # noqa: E402
+np.lib.index_tricks = _it
+import scipy.optimize  # noqa: E402
+import scipy.optimize._linesearch as _ls  # noqa: E402
+_m = types.ModuleType("scipy.optimize.linesearch")
+_m.line_search_armijo = _ls.line_search_armijo
+_m.line_search_wolfe1 = _ls.line_search_wolfe1
+sys.modules["scipy.optimize.linesearch"] = _m
+scipy.optimize.linesearch = _m
+from scipy import sparse, optimize  # noqa: E402
+
+from utilities import geometry, projection_operators, alignment_functions, generate_phantom  # noqa: E402
+from utilities import voxel_utilities  # noqa: E402
+from recon import sirt  # noqa: E402
+
+
+def geom(n_proj, N, cor_shift=None, step=1.0, ndet=None):
+    ndet = N if ndet is None else ndet
+    return geometry.Geometry(n_proj, np.array([N, N, N]), np.ones(3), np.array([ndet, ndet]), np.ones(2),
+                             cor_shift=cor_shift, step_size=step)
+
+
+def csr_canon(A):
+    A = A.copy()
+    A.sum_duplicates()
+    A.sort_indices()
+    return dict(data=A.data, indices=A.indices.astype(np.int32), indptr=A.indptr.astype(np.int64),
+                shape=np.array(A.shape, np.int64))
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print("%-28s %8.1f KB" % (name, os.path.getsize(path) / 1024.))
+
+
+def jitter(rng, n, ang_deg, px):
+    alpha = np.deg2rad(rng.uniform(-ang_deg, ang_deg, n))
+    beta = np.deg2rad(rng.uniform(-ang_deg, ang_deg, n))
+    xyz = np.zeros((n, 3))
+    xyz[:, 0] = rng.uniform(-px, px, n)
+    xyz[:, 2] = rng.uniform(-px, px, n)
+    return alpha, beta, xyz
+
+
+# ------------------------------------------------------------------ G7 phantom
+def g7():
+    out = {}
+    for n in (16, 32):
+        out["shepp%d" % n] = generate_phantom.shepp3d(n)
+    out["params"] = np.asarray(generate_phantom._get_shepp_array())
+    save("g7_phantom", **out)
+
+
+# ------------------------------------------------------------------ G1 assembled operator
+def g1():
+    out = {}
+    # case a: 8^3, default poses (phi = linspace(0,pi,3), includes the degenerate phi=0, pi/2, pi)
+    geo = geom(3, 8)
+    A = projection_operators.ProjectionMatrix(geo).projection_matrix()
+    for k, v in csr_canon(A).items():
+        out["a_" + k] = v
+    # case b: 8^3 generic poses incl. ty, with per-projection cor_shift
+    rng = np.random.default_rng(11)
+    phi = np.array([0.3, 1.1, 2.5])
+    alpha, beta, xyz = jitter(rng, 3, 2.0, 1.5)
+    xyz[:, 1] = rng.uniform(-1, 1, 3)
+    cor = rng.uniform(-1.0, 1.0, (3, 3))
+    geo = geom(3, 8, cor_shift=cor)
+    A = projection_operators.ProjectionMatrix(geo).projection_matrix(alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz)
+    out.update(b_phi=phi, b_alpha=alpha, b_beta=beta, b_xyz=xyz, b_cor=cor)
+    for k, v in csr_canon(A).items():
+        out["b_" + k] = v
+    # case c: 16^3, 2 generic poses, voxel mask, float64 precision, step 0.5, detector 12x12
+    rng = np.random.default_rng(12)
+    phi = np.array([0.7, 2.0])
+    alpha, beta, xyz = jitter(rng, 2, 1.0, 2.0)
+    geo = geom(2, 16, step=0.5, ndet=12)
+    mask = (rng.uniform(size=(16, 16, 16)) > 0.3)
+    A = projection_operators.ProjectionMatrix(geo, precision=np.float64).projection_matrix(
+        alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz, voxel_mask=mask)
+    out.update(c_phi=phi, c_alpha=alpha, c_beta=beta, c_xyz=xyz, c_mask=mask)
+    for k, v in csr_canon(A).items():
+        out["c_" + k] = v
+    # case d: n_proj == 1 re-wrapping path (utilities/projection_operators.py:44-48)
+    geo = geom(1, 8)
+    A = projection_operators.ProjectionMatrix(geo).projection_matrix(phi=np.array([0.4]), alpha=np.array([0.01]),
+                                                                     beta=np.array([-0.02]),
+                                                                     xyz_shift=np.array([[0.5, 0.0, -0.25]]))
+    for k, v in csr_canon(A).items():
+        out["d_" + k] = v
+    save("g1_operator", **out)
+
+
+# ------------------------------------------------------------------ G2 A.x / A^T.y
+def g2_inputs():
+    rng = np.random.default_rng(1)
+    n_proj, N = 6, 32
+    phi = np.linspace(0., np.pi, n_proj)
+    alpha, beta, xyz = jitter(rng, n_proj, 1.0, 2.0)
+    y = rng.standard_normal((n_proj, N * N)).astype(np.float32)
+    return n_proj, N, phi, alpha, beta, xyz, y
+
+
+def g2():
+    n_proj, N, phi, alpha, beta, xyz, y = g2_inputs()
+    x = generate_phantom.shepp3d(N)
+    geo = geom(n_proj, N)
+    A = projection_operators.ProjectionMatrix(geo).projection_matrix(alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz)
+    Ax = sparse.csr_matrix.dot(A, x.ravel())
+    ATy = sparse.csc_matrix.dot(sparse.csr_matrix.transpose(A), y.ravel())
+    # unperturbed (degenerate) set as well: phi = linspace incl. 0, pi
+    A0 = projection_operators.ProjectionMatrix(geo).projection_matrix()
+    Ax0 = sparse.csr_matrix.dot(A0, x.ravel())
+    ATy0 = sparse.csc_matrix.dot(sparse.csr_matrix.transpose(A0), y.ravel())
+    save("g2_fwd_adj", phi=phi, alpha=alpha, beta=beta, xyz=xyz, y=y, Ax=Ax, ATy=ATy, Ax0=Ax0, ATy0=ATy0,
+         nnz=np.array([A.nnz, A0.nnz]))
+
+
+# ------------------------------------------------------------------ G3 projection_gradient
+def g3_poses():
+    rng = np.random.default_rng(3)
+    phi = np.array([0.45, 1.3, 2.6, 0.0])
+    alpha = np.append(np.deg2rad(rng.uniform(-2, 2, 3)), 0.0)
+    beta = np.append(np.deg2rad(rng.uniform(-2, 2, 3)), 0.0)
+    xyz = np.zeros((4, 3))
+    xyz[:3] = rng.uniform(-2.5, 2.5, (3, 3))
+    cor = np.zeros((4, 3))
+    cor[:3, 0] = rng.uniform(-1.5, 1.5, 3)
+    return phi, alpha, beta, xyz, cor
+
+
+def g3():
+    N = 32
+    x = generate_phantom.shepp3d(N)
+    phi, alpha, beta, xyz, cor = g3_poses()
+    geo = geom(1, N)
+    P = projection_operators.ProjectionMatrix(geo, precision=np.float64)
+    projs, grads = [], []
+    for i in range(4):
+        p, g = P.projection_gradient(x, alpha[i], beta[i], phi[i], xyz[i], cor[i])
+        projs.append(p)
+        grads.append(g)
+    save("g3_proj_grad", phi=phi, alpha=alpha, beta=beta, xyz=xyz, cor=cor, proj=np.array(projs), grad=np.array(grads))
+
+
+# ------------------------------------------------------------------ G4 matrix-free Fortran (float32)
+def g4():
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_mf.so"))
+    n_proj, N, phi, alpha, beta, xyz, y = g2_inputs()
+    x = generate_phantom.shepp3d(N).astype(np.float32)
+    geo = geom(n_proj, N)
+    n_rays, n_vox = geo.n_det, geo.n_vox
+    f32 = np.float32
+    F = lambda a: np.asfortranarray(a, dtype=f32)  # noqa: E731
+    I = lambda v: ctypes.byref(ctypes.c_int32(int(v)))  # noqa: E731
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    al, be, ph = F(alpha), F(beta), F(phi)
+    xyzT, corT = F(xyz.T), F(np.zeros((3, n_proj)))
+    src, det, org = F(geo.source_centers), F(geo.det_centers), F(geo.vox_origin)
+    step = ctypes.byref(ctypes.c_float(1.0))
+    rec = F(x.ravel())
+    # forward_project(alpha,beta,phi,xyz,cor_shift,source_points,detector_points,origin,step_size,nx,ny,nz,recon,n_proj,n_rays,n_vox,ax)
+    ax = np.zeros((n_proj, n_rays), dtype=f32, order="F")
+    lib.forward_project_(P(al), P(be), P(ph), P(xyzT), P(corT), P(src), P(det), P(org), step, I(N), I(N), I(N),
+                         P(rec), I(n_proj), I(n_rays), I(n_vox), P(ax))
+    # back_project(alpha,beta,phi,xyz,voxel_centers,origin,det_image,n_proj,n_vox,n_det_x,n_det_z,atx)
+    det_img = np.asfortranarray(y.reshape(n_proj, N, N), dtype=f32)
+    vc = F(geo.vox_centers)
+    atx = np.zeros(n_vox, dtype=f32)
+    lib.back_project_(P(al), P(be), P(ph), P(xyzT), P(vc), P(org), P(det_img), I(n_proj), I(n_vox), I(N), I(N), P(atx))
+    # compute_gradient(alpha,beta,phi,xyz,cor_shift,source_points,detector_points,origin,step_size,nx,ny,nz,recon,n_rays,n_vox,ax,dax)
+    gphi, galpha, gbeta, gxyz, gcor = g3_poses()
+    axs, daxs = [], []
+    for i in range(4):
+        a1 = np.zeros(n_rays, dtype=f32)
+        d1 = np.zeros((6, n_rays), dtype=f32, order="F")
+        lib.compute_gradient_(ctypes.byref(ctypes.c_float(galpha[i])), ctypes.byref(ctypes.c_float(gbeta[i])),
+                              ctypes.byref(ctypes.c_float(gphi[i])), P(F(gxyz[i])), P(F(gcor[i])), P(src), P(det),
+                              P(org), step, I(N), I(N), I(N), P(rec), I(n_rays), I(n_vox), P(a1), P(d1))
+        axs.append(a1.copy())
+        daxs.append(np.array(d1))
+    save("g4_matrix_free", ax=np.ascontiguousarray(ax), atx=atx, grad_ax=np.array(axs), grad_dax=np.array(daxs))
+
+
+# ------------------------------------------------------------------ G5 SIRT
+def g5():
+    N, n_proj = 32, 16
+    rng = np.random.default_rng(5)
+    x = generate_phantom.shepp3d(N)
+    phi = np.linspace(0., np.pi, n_proj)
+    alpha, beta, xyz = jitter(rng, n_proj, 1.0, 2.0)
+    geo = geom(n_proj, N)
+    A = projection_operators.ProjectionMatrix(geo).projection_matrix(alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz)
+    b = sparse.csr_matrix.dot(A, x.ravel()).reshape(n_proj, -1)
+    angles = np.array([phi, alpha, beta]).T
+    out = dict(phi=phi, alpha=alpha, beta=beta, xyz=xyz, b=b)
+    for tag, pos, gt in (("plain", False, None), ("pos_gt", True, x)):
+        opts = {} if gt is None else {"ground_truth": gt.copy()}
+        s = sirt.SIRT(geo, b.copy(), angles, xyz, options=opts)
+        rec, err = s.run_main_iteration(niter=10, positivity=pos)
+        out["rec_" + tag] = np.array(rec, dtype=np.float32)
+        out["err_" + tag] = err
+        out["W"] = s.W
+        out["V"] = s.V
+    save("g5_sirt", **out)
+
+
+# ------------------------------------------------------------------ G6 alignment API
+def g6():
+    N = 32
+    rng = np.random.default_rng(3)
+    x = generate_phantom.shepp3d(N)
+    phi0 = 0.9
+    true = np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), np.deg2rad(rng.uniform(-1, 1)), np.deg2rad(rng.uniform(-1, 1))])
+    geo = geom(1, N)
+    P = projection_operators.ProjectionMatrix(geo)
+    b, _ = P.projection_gradient(x, true[2], true[3], phi0, np.array([true[0], 0., true[1]]), geo.cor_shift[0])
+    import copy
+    this_geo = copy.deepcopy(geo)
+    this_geo.cor_shift = geo.cor_shift[0]
+    ao = alignment_functions.AlignmentUtilities(b.reshape(N, N), P, this_geo)
+    args = (ao, x, np.array([phi0, 0., 0.]), np.zeros(3))
+    out = dict(b=b, phi0=np.array(phi0), true=true)
+    pts = {"zero": np.zeros(4), "gen": np.array([0.4, -0.7, 0.004, -0.006])}
+    for tag, p in pts.items():
+        out["cost_xzab_" + tag] = np.array(alignment_functions.cost_xzab(p, *args))
+        out["grad_xzab_" + tag] = alignment_functions.gradient_xzab(p, *args)
+        p5 = np.array([p[0], p[1], 0.003, p[2], p[3]])
+        out["cost_xzpab_" + tag] = np.array(alignment_functions.cost_xzpab(p5, *args))
+        out["grad_xzpab_" + tag] = alignment_functions.gradient_xzpab(p5, *args)
+        out["p_" + tag] = p
+    sc = np.array([1.0, 2.0, 50.0, 25.0])
+    out["grad_xzab_scaled"] = alignment_functions.gradient_xzab(pts["gen"], *args, scale_factor=sc)
+    out["grad_xzab_vec"] = alignment_functions.gradient_xzab(pts["gen"], *args, return_vector=True)
+    out["cost_xzab_vec"] = alignment_functions.cost_xzab(pts["gen"], *args, return_vector=True)
+    for nm, p in (("xz", [0.4, -0.7]), ("x", [0.4]), ("z", [-0.7]), ("ab", [0.004, -0.006]), ("a", [0.004]),
+                  ("b", [-0.006]), ("xzb", [0.4, -0.7, -0.006])):
+        p = np.array(p)
+        out["cost_%s" % nm] = np.array(getattr(alignment_functions, "cost_" + nm)(p, *args))
+        out["grad_%s" % nm] = getattr(alignment_functions, "gradient_" + nm)(p, *args)
+    res = optimize.minimize(alignment_functions.cost_xzab, np.zeros(4), method="L-BFGS-B",
+                            jac=alignment_functions.gradient_xzab, args=args,
+                            bounds=((-3., 3.), (-3., 3.), (-0.02, 0.02), (-0.02, 0.02)), options={"disp": False})
+    out.update(lbfgs_x=res.x, lbfgs_fun=np.array(res.fun), lbfgs_nfev=np.array(res.nfev))
+    xg, fg, stop = alignment_functions.gradient_descent(np.zeros(4), alignment_functions.cost_xzab,
+                                                        alignment_functions.gradient_xzab,
+                                                        args=args + (None,), options={"maxiter": 5})
+    out.update(gd_x=xg, gd_f=np.array(fg), gd_stop=np.array(stop))
+    save("g6_alignment", **out)
+
+
+# ------------------------------------------------------------------ G8 voxel-driven splat
+def g8():
+    N = 16
+    rng = np.random.default_rng(8)
+    x = generate_phantom.shepp3d(N)
+    phi = np.array([0.6, 2.2])
+    alpha, beta, xyz = jitter(rng, 2, 2.0, 1.5)
+    cor = rng.uniform(-1, 1, (2, 3))
+    out = dict(phi=phi, alpha=alpha, beta=beta, xyz=xyz, cor=cor)
+    for i in range(2):
+        geo = geom(1, N)
+        geo.cor_shift = cor[i]
+        d, r, w = voxel_utilities.forward_sparse(geo, alpha[i], beta[i], phi[i], xyz[i])
+        A = sparse.csr_matrix(sparse.coo_matrix((w, (r, d)), shape=(geo.n_det, geo.n_vox)))
+        for k, v in csr_canon(A).items():
+            out["s%d_%s" % (i, k)] = v
+        img, grad = voxel_utilities.forward_proj_grad(geo, alpha[i], beta[i], phi[i], xyz[i], x.astype(np.float32))
+        out["img%d" % i] = img
+        out["grad%d" % i] = grad
+    save("g8_voxel_splat", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g7", "g1", "g2", "g3", "g4", "g5", "g6", "g8"]
+    for w in which:
+        globals()[w]()
