@@ -1,0 +1,175 @@
+/*
+ * include/tomo.h -- C-ABI of libtomo_hip.so, the MI355X (gfx950) implementation of the
+ * ray-driven projection hot path of pandekan/tomography_alignment.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no framework types.  Each entry point
+ * cites the reference interface it replaces (path:line in the reference tree).  The reference's
+ * native surface is two f2py modules (src/ray_wt_grad.f90, src/vox_wt_grad.f90) plus three
+ * un-wired matrix-free Fortran routines (src/forward_projection.f90, src/back_projection.f90,
+ * src/projection_gradient.f90); a maintainer binds this library with ctypes exactly where
+ * utilities/ray_voxel_utilities.py:3 does `from src import ray_wt_grad`.
+ *
+ * Conventions (all from the reference):
+ *   volume   float32, C order [x][y][z], linear index (ix*ny+iy)*nz+iz   src/ray_wt_grad.f90:38
+ *   detector ray index r = ix*ndz + iz                                    utilities/geometry.py:94-100
+ *   sinogram float32 [n_proj][ndx*ndz]                                    recon/sirt.py:60
+ *   pose     7 doubles per projection: phi, alpha, beta, tx, ty, tz, cor_x
+ *            T(x) = Rz(phi) Rx(alpha) (Ry(beta) x + t), source/detector x first shifted by cor_x
+ *                                                                         utilities/ray_voxel_utilities.py:6-12,72-73
+ *   gradient rows tx, ty, tz, phi, alpha, beta                            utilities/ray_voxel_utilities.py:39-49
+ *
+ * Ownership: `d_*` arguments are device pointers obtained from tomo_malloc (or any hipMalloc'ed
+ * memory of the same device); `h_*` are caller-owned host buffers.  Nothing allocated by the
+ * library is ever returned to the caller except through tomo_malloc.
+ * Errors: every function returns 0 on success or a negative tomo_status; tomo_last_error() gives
+ * text.  (The reference has no error channel at all.)  Out-of-volume samples contribute zero, as in
+ * src/ray_wt_grad.f90:35-89 -- that is semantics, not an error.
+ * Threading: one ctx per GPU per process; calls on a ctx are ordered on its HIP stream.  Compute
+ * entry points are asynchronous w.r.t. the host unless they return host results.
+ */
+#ifndef TOMO_H_
+#define TOMO_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__) || defined(__clang__)
+#define TOMO_API __attribute__((visibility("default")))
+#else
+#define TOMO_API
+#endif
+
+#define TOMO_ABI_VERSION 1
+#define TOMO_POSE_STRIDE 7
+
+typedef struct tomo_ctx tomo_ctx;
+
+typedef enum tomo_status {
+    TOMO_OK = 0,
+    TOMO_ERR_HIP = -1,        /* a HIP runtime call failed (text has hipGetErrorString) */
+    TOMO_ERR_ARG = -2,        /* bad argument / shape */
+    TOMO_ERR_STATE = -3,      /* geometry not set, comm not initialised, ... */
+    TOMO_ERR_RCCL = -4,       /* an RCCL call failed */
+    TOMO_ERR_UNSUPPORTED = -5
+} tomo_status;
+
+/* Mirror of the attributes of utilities/geometry.py:9-105 `Geometry` that the hot path reads. */
+typedef struct tomo_geom {
+    int32_t nx, ny, nz;      /* vox_shape                                   geometry.py:24 */
+    int32_t ndx, ndz;        /* det_shape                                   geometry.py:28 */
+    double vox_origin[3];    /* world coords of voxel (0,0,0) centre        geometry.py:87 */
+    double vox_pitch[3];     /* voxel pitch (only the voxel-driven back-projector reads it; the ray
+                                path, like the reference, takes index = world - origin) geometry.py:25 */
+    double det_x0, det_z0;   /* world x,z of detector pixel (0,0) centre    geometry.py:92-93 */
+    double det_dx, det_dz;   /* detector pixel pitch                        geometry.py:29 */
+    double src_y, det_y;     /* y of the source / detector planes (-sy,+sy) geometry.py:95-96 */
+    double step;             /* ray-march step                              geometry.py:46 */
+} tomo_geom;
+
+/* ---------------------------------------------------------------- context / memory */
+TOMO_API int tomo_abi_version(void);
+TOMO_API int tomo_device_count(int *n);
+TOMO_API int tomo_ctx_create(int device, tomo_ctx **out);
+TOMO_API int tomo_ctx_destroy(tomo_ctx *ctx);
+TOMO_API const char *tomo_last_error(const tomo_ctx *ctx);          /* ctx may be NULL: last global error */
+TOMO_API int tomo_device_name(tomo_ctx *ctx, char *buf, size_t n);
+TOMO_API int tomo_malloc(tomo_ctx *ctx, size_t bytes, void **d_ptr);
+TOMO_API int tomo_free(tomo_ctx *ctx, void *d_ptr);
+TOMO_API int tomo_memcpy_h2d(tomo_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+TOMO_API int tomo_memcpy_d2h(tomo_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+TOMO_API int tomo_memcpy_d2d(tomo_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+TOMO_API int tomo_memset0(tomo_ctx *ctx, void *d_ptr, size_t bytes);
+TOMO_API int tomo_sync(tomo_ctx *ctx);
+/* Integer tuning knobs ("fwd_variant", "adj_variant", ...); unknown keys are TOMO_ERR_ARG. */
+TOMO_API int tomo_set_option(tomo_ctx *ctx, const char *key, int value);
+
+/* Geometry: replaces passing a `Geometry` object to utilities/ray_voxel_utilities.py:53,113. */
+TOMO_API int tomo_set_geometry(tomo_ctx *ctx, const tomo_geom *g);
+
+/* ---------------------------------------------------------------- projectors
+ * tomo_forward: proj[ip, r] = (A x)[ip*n_det + r] for the operator assembled by
+ *   utilities/projection_operators.py:22-76 (ProjectionMatrix.projection_matrix -> _forward_ray ->
+ *   utilities/ray_voxel_utilities.py:53-110 forward_sparse -> src/ray_wt_grad.f90:1-92
+ *   trilinear_ray_sparse), applied as recon/sirt.py:59 `sparse.csr_matrix.dot(A, x)`;
+ *   same semantics as the matrix-free src/forward_projection.f90:1-68 forward_project (which
+ *   ignores cor_shift: pass cor_x = 0 to mimic it).
+ *   d_vol [nx*ny*nz], d_proj [n_proj*ndx*ndz] (overwritten). */
+TOMO_API int tomo_forward(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_vol, float *d_proj);
+
+/* tomo_adjoint: vol = A^T y (accumulate != 0: vol += A^T y) -- the exact transpose of the weights
+ *   of src/ray_wt_grad.f90:35-89, i.e. recon/sirt.py:61
+ *   `sparse.csc_matrix.dot(sparse.csr_matrix.transpose(A), y)`. */
+TOMO_API int tomo_adjoint(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_proj, float *d_vol,
+                 int accumulate);
+
+/* tomo_backproject_voxel: the voxel-driven bilinear back-projector src/back_projection.f90:1-34
+ *   (voxel_rigid_transformation + voxel_back_bilinear, src/external_back_projection.f90:1-68):
+ *   x' = Ry(beta)(Rx(alpha) Rz(phi) c + t), bilinear gather at (x'_x - origin_x, x'_z - origin_z).
+ *   NOT the adjoint of tomo_forward (SURVEY 8a quirk vii).  cor_x of the pose is ignored.
+ *   d_det [n_proj][ndx][ndz], d_vol overwritten. */
+TOMO_API int tomo_backproject_voxel(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_det,
+                           float *d_vol);
+
+/* tomo_proj_grad: projection and its 6-DoF pose gradient for ONE projection --
+ *   utilities/projection_operators.py:112-122 projection_gradient ->
+ *   utilities/ray_voxel_utilities.py:113-170 forward_proj_grad -> src/ray_wt_grad.f90:95-223
+ *   trilinear_ray_interp; float32 twin src/projection_gradient.f90:1-79 compute_gradient.
+ *   d_proj [n_det], d_grad [6][n_det].  row_order 0: tx,ty,tz,phi,alpha,beta (Python API);
+ *   row_order 1: tx,ty,tz,alpha,beta,phi (src/external_forward_projection.f90:56-69). */
+TOMO_API int tomo_proj_grad(tomo_ctx *ctx, const double *h_pose, const float *d_vol, float *d_proj,
+                   float *d_grad, int row_order);
+
+/* tomo_cost_grad: fused alignment evaluation for n projections (batched form of
+ *   utilities/alignment_functions.py:16-37 AlignmentUtilities.cost/.gradient followed by the
+ *   reductions of :124 and :146): residual = b - proj, cost = 0.5*||residual||^2,
+ *   grad6[k] = sum_r (-dproj/dp_k)[r] * residual[r]   (rows tx,ty,tz,phi,alpha,beta).
+ *   d_b [n][n_det]; h_cost [n], h_grad6 [n][6] (host, double).  d_resid may be NULL or [n][n_det]. */
+TOMO_API int tomo_cost_grad(tomo_ctx *ctx, const double *h_poses, int n, const float *d_vol, const float *d_b,
+                   double *h_cost, double *h_grad6, float *d_resid);
+
+/* tomo_triplets: COO triplets of one projection with the emission order and values of
+ *   src/ray_wt_grad.f90:1-92 trilinear_ray_sparse (ray-major, sample, corner; float64 weights).
+ *   Call with h_dat == NULL to get the count.  Intended for N <= 128. */
+TOMO_API int tomo_triplets(tomo_ctx *ctx, const double *h_pose, int64_t capacity, int32_t *h_dat, int32_t *h_det,
+                  double *h_wts, int64_t *n_inds);
+
+/* ---------------------------------------------------------------- solver vector kernels
+ * (device-resident forms of the numpy lines of recon/sirt.py:33-40,60-73 and recon/cgls.py:56-82) */
+TOMO_API int tomo_vec_recip_guard(tomo_ctx *ctx, float *d_v, int64_t n, float thresh, int strict_zero); /* sirt.py:37-40 / sirt_mpi.py:69-72 */
+TOMO_API int tomo_vec_fill(tomo_ctx *ctx, float *d_v, int64_t n, float value);
+TOMO_API int tomo_vec_residual_scale(tomo_ctx *ctx, const float *d_b, const float *d_ax, const float *d_w,
+                            float *d_out, int64_t n, double *h_sumsq); /* out = w*(b-ax); sumsq = ||b-ax||^2  sirt.py:60-61,69 */
+TOMO_API int tomo_vec_update(tomo_ctx *ctx, float *d_rec, const float *d_bp, const float *d_v, int64_t n,
+                    int positivity, const float *d_gt, double *h_sumsq_err); /* rec += v*bp; clamp; ||gt-rec||^2  sirt.py:63-67,73 */
+TOMO_API int tomo_vec_axpy(tomo_ctx *ctx, float *d_y, const float *d_x, float a, int64_t n);          /* y += a*x */
+TOMO_API int tomo_vec_xpay(tomo_ctx *ctx, float *d_y, const float *d_x, float a, int64_t n);          /* y = x + a*y   cgls.py:78 */
+TOMO_API int tomo_vec_sub(tomo_ctx *ctx, float *d_out, const float *d_a, const float *d_b, int64_t n); /* out = a-b */
+TOMO_API int tomo_vec_mul(tomo_ctx *ctx, float *d_y, const float *d_x, int64_t n);                     /* y *= x */
+TOMO_API int tomo_vec_dot(tomo_ctx *ctx, const float *d_a, const float *d_b, int64_t n, double *h_dot);
+TOMO_API int tomo_vec_diff_sumsq(tomo_ctx *ctx, const float *d_a, const float *d_b, int64_t n, double *h_sumsq);
+
+/* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI)
+ * Replaces mpi4py COMM_WORLD Allreduce(SUM) of recon/sirt_mpi.py:68,103 and recon/cgls_mpi.py:55,98
+ * and the scalar allreduce of recon/sirt_mpi.py:110. */
+#define TOMO_COMM_ID_BYTES 128
+TOMO_API int tomo_comm_get_unique_id(void *h_id128);
+TOMO_API int tomo_comm_init(tomo_ctx *ctx, const void *h_id128, int n_ranks, int rank);
+TOMO_API int tomo_comm_destroy(tomo_ctx *ctx);
+TOMO_API int tomo_allreduce_sum_f32(tomo_ctx *ctx, float *d_buf, int64_t n);     /* in place, on ctx stream */
+TOMO_API int tomo_allreduce_sum_f64_host(tomo_ctx *ctx, double *h_vals, int n);  /* small host scalars */
+TOMO_API int tomo_allreduce_max_f64_host(tomo_ctx *ctx, double *h_vals, int n);
+
+/* ---------------------------------------------------------------- measurement (HIP events on the ctx stream) */
+TOMO_API int tomo_timer_start(tomo_ctx *ctx);
+TOMO_API int tomo_timer_stop(tomo_ctx *ctx, float *h_ms);            /* synchronises */
+TOMO_API int tomo_profile_enable(tomo_ctx *ctx, int on);              /* bracket every kernel launch with events */
+TOMO_API int tomo_profile_reset(tomo_ctx *ctx);
+TOMO_API int tomo_profile_get(tomo_ctx *ctx, const char *kernel, int64_t *n_launch, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOMO_H_ */

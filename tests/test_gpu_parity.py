@@ -1,0 +1,231 @@
+"""GPU parity tests: the HIP path (through the C-ABI of libtomo_hip.so) against
+  * the golden vectors produced by the compiled reference (tests/golden), and
+  * the CPU oracle on the same seeded inputs,
+plus size-independent properties at larger sizes.  Tolerance: 1e-5 relative (max|a-b|/max|b|),
+the float32 bar of BASELINE.json:north_star."""
+import numpy as np
+import pytest
+
+from conftest import golden, rel_max, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def geo_pair(n_proj, N, cor_shift=None, step=1.0, ndet=None, shape=None):
+    from tomography_alignment_amd.utilities.geometry import Geometry
+    from oracle import oracle as orc
+    shape = np.array([N, N, N]) if shape is None else np.array(shape)
+    ndet = np.array([N, N]) if ndet is None else np.array(ndet)
+    args = (n_proj, shape, np.ones(3), ndet, np.ones(2))
+    return Geometry(*args, cor_shift=cor_shift, step_size=step), orc.Geo(*args, cor_shift=cor_shift, step_size=step)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def PM():
+    from tomography_alignment_amd.utilities.projection_operators import ProjectionMatrix
+    return ProjectionMatrix
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_forward_adjoint_vs_reference_golden(PM, shepp32, variant):
+    g = golden("g2_fwd_adj")
+    geo, _ = geo_pair(6, 32)
+    P = PM(geo)
+    P.backend.ctx.set_option("fwd_variant", variant)
+    A = P.projection_matrix(alpha=g["alpha"], beta=g["beta"], phi=g["phi"], xyz_shift=g["xyz"])
+    assert A.shape == (6 * 32 * 32, 32 ** 3)
+    Ax = A.dot(shepp32.ravel())
+    assert Ax.dtype == np.float32
+    assert rel_max(Ax, g["Ax"]) < TOL
+    ATy = A.T.dot(g["y"].ravel())
+    assert rel_max(ATy, g["ATy"]) < TOL
+    A0 = P.projection_matrix()          # unperturbed poses (phi = 0, pi/2, pi among them: integer coordinates)
+    assert rel_max(A0.dot(shepp32.ravel()), g["Ax0"]) < TOL
+    assert rel_max(A0.T.dot(g["y"].ravel()), g["ATy0"]) < TOL
+    P.backend.ctx.set_option("fwd_variant", 2)
+
+
+def test_scipy_unbound_protocol(PM, shepp32):
+    """recon/sirt.py:59,61 call the operator through scipy's unbound methods."""
+    from scipy import sparse
+    g = golden("g2_fwd_adj")
+    geo, _ = geo_pair(6, 32)
+    A = PM(geo).projection_matrix(alpha=g["alpha"], beta=g["beta"], phi=g["phi"], xyz_shift=g["xyz"])
+    Ax = sparse.csr_matrix.dot(A, shepp32.ravel())
+    ATy = sparse.csc_matrix.dot(sparse.csr_matrix.transpose(A), g["y"].ravel())
+    assert rel_max(Ax, g["Ax"]) < TOL and rel_max(ATy, g["ATy"]) < TOL
+
+
+def test_operator_matches_reference_csr_columns(PM):
+    """G1: apply the matrix-free operator to unit vectors and compare with the reference's CSR."""
+    from scipy import sparse
+    g = golden("g1_operator")
+    ref = sparse.csr_matrix((g["b_data"], g["b_indices"], g["b_indptr"]), shape=tuple(g["b_shape"]))
+    geo, _ = geo_pair(3, 8, cor_shift=g["b_cor"])
+    A = PM(geo).projection_matrix(alpha=g["b_alpha"], beta=g["b_beta"], phi=g["b_phi"], xyz_shift=g["b_xyz"])
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((8 ** 3, 4)).astype(np.float32)
+    for k in range(4):
+        assert rel_max(A.dot(X[:, k]), ref.dot(X[:, k])) < TOL
+    Y = rng.standard_normal((3 * 64, 4)).astype(np.float32)
+    for k in range(4):
+        assert rel_max(A.T.dot(Y[:, k]), ref.T.dot(Y[:, k])) < TOL
+    dense = ref.toarray()
+    cols = [0, 73, 200, 511]
+    for c in cols:
+        e = np.zeros(512, np.float32)
+        e[c] = 1.0
+        assert np.max(np.abs(A.dot(e) - dense[:, c])) < 1e-6
+
+
+def test_voxel_mask_step_and_detector_shape(PM, orc):
+    """G1 case c: voxel mask, step 0.5, detector 12x12 on a 16^3 volume, float64 precision."""
+    from scipy import sparse
+    g = golden("g1_operator")
+    ref = sparse.csr_matrix((g["c_data"], g["c_indices"], g["c_indptr"]), shape=tuple(g["c_shape"]))
+    geo, _ = geo_pair(2, 16, step=0.5, ndet=[12, 12])
+    A = PM(geo, precision=np.float64).projection_matrix(alpha=g["c_alpha"], beta=g["c_beta"], phi=g["c_phi"],
+                                                        xyz_shift=g["c_xyz"], voxel_mask=g["c_mask"])
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(16 ** 3)
+    y = rng.standard_normal(2 * 144)
+    out = A.dot(x)
+    assert out.dtype == np.float64
+    assert rel_max(out, ref.dot(x)) < TOL
+    assert rel_max(A.T.dot(y), ref.T.dot(y)) < TOL
+
+
+def test_projection_gradient_vs_reference_golden(PM, shepp32):
+    g = golden("g3_proj_grad")
+    geo, _ = geo_pair(1, 32)
+    P = PM(geo, precision=np.float64)
+    for i in range(3):          # generic poses
+        p, gr = P.projection_gradient(shepp32, g["alpha"][i], g["beta"][i], g["phi"][i], g["xyz"][i], g["cor"][i])
+        assert gr.shape == (6, 1024)
+        assert rel_max(p, g["proj"][i]) < TOL
+        for k in range(6):
+            assert rel_max(gr[k], g["grad"][i][k]) < TOL, (i, k)
+    # degenerate pose: the value is continuous across integer coordinates, the gradient is not
+    p, gr = P.projection_gradient(shepp32, g["alpha"][3], g["beta"][3], g["phi"][3], g["xyz"][3], g["cor"][3])
+    assert rel_max(p, g["proj"][3]) < TOL
+
+
+def test_fortran_row_order_and_matrix_free_golden(PM, shepp32):
+    """G4: forward_project_, back_project_, compute_gradient_ of the flang-built reference."""
+    from tomography_alignment_amd import _lib
+    g2, g3, g4 = golden("g2_fwd_adj"), golden("g3_proj_grad"), golden("g4_matrix_free")
+    geo, _ = geo_pair(6, 32)
+    P = PM(geo)
+    be = P.backend
+    A = P.projection_matrix(alpha=g2["alpha"], beta=g2["beta"], phi=g2["phi"], xyz_shift=g2["xyz"])
+    assert rel_max(A.dot(shepp32.ravel()), g4["ax"].ravel()) < TOL           # A5
+    poses = _lib.poses_array(g2["phi"], g2["alpha"], g2["beta"], g2["xyz"], np.zeros(3))
+    det = be.upload(g2["y"])
+    vol = be.empty(32 ** 3)
+    be.backproject_voxel(poses, det, vol)
+    # A6: the Fortran rotates voxel centres in float32 (ulp 2e-6 at |x|~16): bilinear weights differ by ~1e-5
+    assert rel_max(vol.download(), g4["atx"]) < 3e-5
+    vdev = be.upload(shepp32)
+    pr, gd = be.empty(1024), be.empty(6 * 1024)
+    for i in range(3):                                                          # A7 row order tx,ty,tz,alpha,beta,phi
+        pose = _lib.poses_array([g3["phi"][i]], [g3["alpha"][i]], [g3["beta"][i]], g3["xyz"][i], g3["cor"][i])
+        be.proj_grad(pose, vdev, pr, gd, 1)
+        assert rel_max(pr.download(), g4["grad_ax"][i]) < TOL
+        mine = gd.download().reshape(6, -1)
+        ref64 = g3["grad"][i][[0, 1, 2, 4, 5, 3]]
+        assert rel_max(mine, ref64) < TOL                  # vs the f64 reference, permuted rows
+        assert rel_l2(mine, g4["grad_dax"][i]) < 2e-3      # the f32 Fortran twin itself is only this close
+
+
+def test_cost_grad_fused_vs_oracle(PM, orc, shepp32):
+    from tomography_alignment_amd import _lib
+    g = golden("g3_proj_grad")
+    geo, og = geo_pair(1, 32)
+    P = PM(geo)
+    be = P.backend
+    rng = np.random.default_rng(4)
+    n = 3
+    b = np.zeros((n, 1024), np.float32)
+    want_c, want_g = [], []
+    for i in range(n):
+        p, gr = orc.projection_gradient(og, shepp32, g["alpha"][i], g["beta"][i], g["phi"][i], g["xyz"][i], g["cor"][i])
+        b[i] = p + 0.05 * rng.standard_normal(1024).astype(np.float32)
+        res = b[i].astype(np.float64) - p
+        want_c.append(0.5 * np.dot(res, res))
+        want_g.append(np.dot(-gr.astype(np.float64), res))
+    poses = _lib.poses_array(g["phi"][:n], g["alpha"][:n], g["beta"][:n], g["xyz"][:n], g["cor"][:n])
+    resid = be.empty(n * 1024)
+    cost, g6 = be.cost_grad(poses, be.upload(shepp32), be.upload(b), resid)
+    assert np.allclose(cost, want_c, rtol=1e-5)
+    assert rel_max(g6, np.array(want_g)) < TOL
+    r = resid.download().reshape(n, -1)
+    assert rel_max(r[0], b[0] - orc.projection_gradient(og, shepp32, g["alpha"][0], g["beta"][0], g["phi"][0], g["xyz"][0], g["cor"][0])[0]) < 1e-4
+
+
+@pytest.mark.parametrize("shape,ndet,step,n_proj", [((20, 24, 70), (20, 70), 1.0, 3),     # ragged, nz > 64, not multiple of 64
+                                                    ((16, 16, 5), (16, 5), 1.0, 2),       # nz << 64
+                                                    ((24, 24, 24), (30, 40), 0.7, 2),     # detector larger than volume, odd step
+                                                    ((33, 31, 65), (33, 65), 1.0, 1)])    # single projection, odd sizes
+def test_edge_shapes_vs_oracle(PM, orc, shape, ndet, step, n_proj):
+    rng = np.random.default_rng(7)
+    geo, og = geo_pair(n_proj, None, step=step, ndet=ndet, shape=shape)
+    phi = rng.uniform(0, np.pi, n_proj)
+    alpha = np.deg2rad(rng.uniform(-3, 3, n_proj))
+    beta = np.deg2rad(rng.uniform(-3, 3, n_proj))
+    xyz = rng.uniform(-3, 3, (n_proj, 3))
+    x = rng.uniform(0, 1, shape).astype(np.float32)
+    y = rng.standard_normal(n_proj * ndet[0] * ndet[1]).astype(np.float32)
+    for variant in (1, 2):
+        P = PM(geo)
+        P.backend.ctx.set_option("fwd_variant", variant)
+        A = P.projection_matrix(alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz)
+        want = orc.forward(og, x, alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz).ravel()
+        assert rel_max(A.dot(x.ravel()), want) < TOL
+        wantT = orc.adjoint(og, y, alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz)
+        assert rel_max(A.T.dot(y), wantT) < TOL
+
+
+def test_rays_missing_the_volume_give_zero(PM):
+    geo, _ = geo_pair(2, 16)
+    A = PM(geo).projection_matrix(phi=np.array([0.3, 1.0]), xyz_shift=np.array([[40., 0., 0.], [0., 0., -50.]]))
+    out = A.dot(np.ones(16 ** 3, np.float32))
+    assert np.all(out == 0.0)
+    assert np.all(A.T.dot(np.ones(2 * 256, np.float32)) == 0.0)
+
+
+def test_properties_at_256(PM):
+    """Config 2 size (256^3): adjointness <Ax,y> = <x,A^T y>, linearity, variant agreement."""
+    N, n_proj = 256, 8
+    rng = np.random.default_rng(2)
+    geo, _ = geo_pair(n_proj, N)
+    phi = np.linspace(0, np.pi, n_proj)
+    alpha = np.deg2rad(rng.uniform(-1, 1, n_proj))
+    beta = np.deg2rad(rng.uniform(-1, 1, n_proj))
+    xyz = np.zeros((n_proj, 3))
+    xyz[:, 0] = rng.uniform(-2, 2, n_proj)
+    xyz[:, 2] = rng.uniform(-2, 2, n_proj)
+    P = PM(geo)
+    A = P.projection_matrix(alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz)
+    x1 = rng.uniform(0, 1, N ** 3).astype(np.float32)
+    x2 = rng.uniform(0, 1, N ** 3).astype(np.float32)
+    y = rng.uniform(0, 1, n_proj * N * N).astype(np.float32)
+    Ax1, Ax2 = A.dot(x1), A.dot(x2)
+    ATy = A.T.dot(y)
+    lhs = np.dot(Ax1.astype(np.float64), y.astype(np.float64))
+    rhs = np.dot(x1.astype(np.float64), ATy.astype(np.float64))
+    assert abs(lhs - rhs) / abs(lhs) < 1e-5
+    assert rel_max(A.dot(x1 + 2 * x2), Ax1 + 2 * Ax2) < TOL
+    P.backend.ctx.set_option("fwd_variant", 1)
+    assert rel_max(A.dot(x1), Ax1) < 1e-6
+    P.backend.ctx.set_option("fwd_variant", 2)
+    # row sums of a ray through the full volume ~ path length: every central ray of an axis-aligned view crosses N voxels
+    A0 = P.projection_matrix(phi=np.array([0.0]))
+    ones = A0.dot(np.ones(N ** 3, np.float32)).reshape(N, N)
+    assert np.allclose(ones[8:-8, 8:-8], N, rtol=1e-5)

@@ -1,0 +1,135 @@
+"""
+Device backend used by the operator and the solvers: a thin object over the C-ABI (include/tomo.h).
+
+The solvers (recon/sirt.py, recon/cgls.py, their sharded twins) are written against this small
+interface -- buffers in, buffers out, scalars back -- so that their control flow (stop rules, guards,
+re-initialisation) can be exercised in CPU-only tests by injecting a stand-in with the same methods
+(tests/backends.py).  The product only ever constructs HipBackend; nothing here falls back to CPU.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+_c_vp = ctypes.c_void_p
+
+
+class HipBackend(object):
+    name = "hip"
+
+    def __init__(self, geometry, ctx=None):
+        self.ctx = ctx if ctx is not None else _lib.Context()
+        self.lib = self.ctx.lib
+        self.geometry = geometry
+        self.n_vox = int(np.prod(geometry.vox_shape))
+        self.n_det = int(np.prod(geometry.det_shape))
+        self.ctx.set_geometry(geometry)
+        self.comm = None
+
+    # ---- buffers
+    def upload(self, host):
+        return self.ctx.to_device(np.asarray(host).ravel(), np.float32)
+
+    def download(self, buf):
+        return buf.download()
+
+    def zeros(self, n):
+        return self.ctx.zeros((int(n),), np.float32)
+
+    def empty(self, n):
+        return self.ctx.empty((int(n),), np.float32)
+
+    def copy(self, dst, src):
+        dst.copy_from(src)
+
+    def is_buffer(self, x):
+        return isinstance(x, _lib.DeviceArray)
+
+    def _geom(self):
+        self.ctx.set_geometry(self.geometry)     # no-op unless another operator changed it
+
+    # ---- projectors (poses: (n,7) float64, see _lib.poses_array)
+    def forward(self, poses, vol, out):
+        self._geom()
+        n = poses.shape[0]
+        if vol.size != self.n_vox or out.size != n * self.n_det:
+            raise ValueError("forward: buffer sizes do not match geometry")
+        self.ctx.check(self.lib.tomo_forward(self.ctx.handle, _lib.dptr(poses), n, vol.ptr, out.ptr))
+        return out
+
+    def adjoint(self, poses, proj, out, accumulate=False):
+        self._geom()
+        n = poses.shape[0]
+        if out.size != self.n_vox or proj.size != n * self.n_det:
+            raise ValueError("adjoint: buffer sizes do not match geometry")
+        self.ctx.check(self.lib.tomo_adjoint(self.ctx.handle, _lib.dptr(poses), n, proj.ptr, out.ptr, 1 if accumulate else 0))
+        return out
+
+    def backproject_voxel(self, poses, det, out):
+        self._geom()
+        n = poses.shape[0]
+        if out.size != self.n_vox or det.size != n * self.n_det:
+            raise ValueError("backproject_voxel: buffer sizes do not match geometry")
+        self.ctx.check(self.lib.tomo_backproject_voxel(self.ctx.handle, _lib.dptr(poses), n, det.ptr, out.ptr))
+        return out
+
+    def proj_grad(self, pose, vol, proj_out, grad_out, row_order=0):
+        self._geom()
+        self.ctx.check(self.lib.tomo_proj_grad(self.ctx.handle, _lib.dptr(pose), vol.ptr, proj_out.ptr, grad_out.ptr, row_order))
+
+    def cost_grad(self, poses, vol, b, resid=None):
+        """-> (cost[n], grad6[n,6]) float64 on the host (fused residual / cost / gradient reduction)."""
+        self._geom()
+        n = poses.shape[0]
+        cost = np.zeros(n, np.float64)
+        g6 = np.zeros((n, 6), np.float64)
+        self.ctx.check(self.lib.tomo_cost_grad(self.ctx.handle, _lib.dptr(poses), n, vol.ptr, b.ptr, _lib.dptr(cost), _lib.dptr(g6),
+                                               resid.ptr if resid is not None else None))
+        return cost, g6
+
+    # ---- solver vector kernels
+    def fill(self, buf, value):
+        self.ctx.check(self.lib.tomo_vec_fill(self.ctx.handle, buf.ptr, buf.size, float(value)))
+
+    def recip_guard(self, buf, thresh=None):
+        """x -> 1/x with x==0 -> 0 (thresh None; recon/sirt.py:37-40) or x<thresh -> 0 (recon/sirt_mpi.py:69-72)."""
+        strict = thresh is None
+        self.ctx.check(self.lib.tomo_vec_recip_guard(self.ctx.handle, buf.ptr, buf.size, 0.0 if strict else float(thresh), 1 if strict else 0))
+
+    def residual_scale(self, b, ax, w, out):
+        s = ctypes.c_double(0)
+        self.ctx.check(self.lib.tomo_vec_residual_scale(self.ctx.handle, b.ptr, ax.ptr, w.ptr if w is not None else None, out.ptr,
+                                                        b.size, ctypes.byref(s)))
+        return s.value
+
+    def update(self, rec, bp, v, positivity=False, gt=None):
+        s = ctypes.c_double(0)
+        self.ctx.check(self.lib.tomo_vec_update(self.ctx.handle, rec.ptr, bp.ptr, v.ptr if v is not None else None, rec.size,
+                                                1 if positivity else 0, gt.ptr if gt is not None else None, ctypes.byref(s)))
+        return s.value if gt is not None else None
+
+    def axpy(self, y, x, a):
+        self.ctx.check(self.lib.tomo_vec_axpy(self.ctx.handle, y.ptr, x.ptr, float(a), y.size))
+
+    def xpay(self, y, x, a):
+        self.ctx.check(self.lib.tomo_vec_xpay(self.ctx.handle, y.ptr, x.ptr, float(a), y.size))
+
+    def sub(self, out, a, b):
+        self.ctx.check(self.lib.tomo_vec_sub(self.ctx.handle, out.ptr, a.ptr, b.ptr, out.size))
+
+    def mul(self, y, x):
+        self.ctx.check(self.lib.tomo_vec_mul(self.ctx.handle, y.ptr, x.ptr, y.size))
+
+    def dot(self, a, b):
+        s = ctypes.c_double(0)
+        self.ctx.check(self.lib.tomo_vec_dot(self.ctx.handle, a.ptr, b.ptr, a.size, ctypes.byref(s)))
+        return s.value
+
+    def diff_sumsq(self, a, b):
+        s = ctypes.c_double(0)
+        self.ctx.check(self.lib.tomo_vec_diff_sumsq(self.ctx.handle, a.ptr, b.ptr, a.size, ctypes.byref(s)))
+        return s.value
+
+    def sync(self):
+        self.ctx.sync()

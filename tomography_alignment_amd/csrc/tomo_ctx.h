@@ -1,0 +1,84 @@
+// tomo_ctx.h -- internal context shared by the translation units of libtomo_hip.so
+#ifndef TOMO_CTX_H_
+#define TOMO_CTX_H_
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/tomo.h"
+#include "tomo_raycore.h"
+
+struct BpC {   // voxel-driven back-projector constants of one projection (src/external_back_projection.f90:17-25,45-48)
+    double u0, ux, uy, uz;   // detector-x coordinate (index units) = u0 + ix*ux + iy*uy + iz*uz
+    double v0, vx, vy, vz;   // detector-z coordinate
+};
+
+struct ProfRec { int64_t n = 0; double ms = 0.0; };
+struct ProfPending { std::string name; hipEvent_t e0, e1; };
+
+struct tomo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool has_geom = false;
+    TomoGeomC g{};
+    double vox_pitch[3] = {1, 1, 1};
+    // padded scratch volume (zero halo) and its state
+    float *d_volpad = nullptr;
+    size_t volpad_elems = 0;
+    bool halo_dirty = true;
+    // per-projection constants (pinned host staging + device)
+    void *h_stage = nullptr;
+    void *d_stage = nullptr;
+    size_t stage_bytes = 0;
+    // reduction scratch
+    double *d_red = nullptr;
+    double *h_red = nullptr;
+    size_t red_cap = 0;     // doubles
+    // options
+    int fwd_variant = 2;
+    int adj_variant = 2;
+    int adj_batch = 0;      // 0 = auto
+    // timing / profiling
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profile_on = false;
+    std::map<std::string, ProfRec> prof;
+    std::vector<ProfPending> pending;
+    std::vector<hipEvent_t> ev_pool;
+    // comm
+    ncclComm_t comm = nullptr;
+    int n_ranks = 1, rank = 0;
+    std::string err;
+};
+
+int tomo_fail(tomo_ctx *ctx, int code, const std::string &msg);
+int tomo_ensure_stage(tomo_ctx *ctx, size_t bytes);
+int tomo_ensure_red(tomo_ctx *ctx, size_t n_doubles);
+void tomo_prof_begin(tomo_ctx *ctx, const char *name);
+void tomo_prof_end(tomo_ctx *ctx);
+
+#define TOMO_HIP(ctx, call)                                                                         \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return tomo_fail((ctx), TOMO_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define TOMO_NEED_GEOM(ctx)                                                              \
+    do {                                                                                 \
+        if (!(ctx)) return tomo_fail(nullptr, TOMO_ERR_ARG, "null ctx");                 \
+        if (!(ctx)->has_geom) return tomo_fail((ctx), TOMO_ERR_STATE, "geometry not set"); \
+    } while (0)
+
+// launch with optional event bracketing (tomo_profile_enable) and launch-error check
+#define TOMO_LAUNCH(ctx, name, kern, grid, block, shmem, ...)                                   \
+    do {                                                                                        \
+        tomo_prof_begin((ctx), (name));                                                         \
+        hipLaunchKernelGGL(kern, (grid), (block), (shmem), (ctx)->stream, __VA_ARGS__);         \
+        tomo_prof_end((ctx));                                                                   \
+        TOMO_HIP((ctx), hipGetLastError());                                                     \
+    } while (0)
+
+#endif

@@ -1,0 +1,546 @@
+// tomo_ctx.hip -- context, device memory, geometry, profiling, solver vector kernels, RCCL.
+// (Projection kernels live in tomo_project.hip.)
+#include <string.h>
+
+#include <algorithm>
+
+#include "tomo_ctx.h"
+
+static std::string g_last_error;
+
+int tomo_fail(tomo_ctx *ctx, int code, const std::string &msg)
+{
+    g_last_error = msg;
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+extern "C" int tomo_abi_version(void) { return TOMO_ABI_VERSION; }
+
+extern "C" const char *tomo_last_error(const tomo_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+extern "C" int tomo_device_count(int *n)
+{
+    if (!n) return tomo_fail(nullptr, TOMO_ERR_ARG, "null n");
+    TOMO_HIP(nullptr, hipGetDeviceCount(n));
+    return TOMO_OK;
+}
+
+extern "C" int tomo_ctx_create(int device, tomo_ctx **out)
+{
+    if (!out) return tomo_fail(nullptr, TOMO_ERR_ARG, "null out");
+    *out = nullptr;
+    TOMO_HIP(nullptr, hipSetDevice(device));
+    tomo_ctx *c = new tomo_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) {
+        std::string m = std::string("ctx_create: ") + hipGetErrorString(e);
+        delete c;
+        return tomo_fail(nullptr, TOMO_ERR_HIP, m);
+    }
+    *out = c;
+    return TOMO_OK;
+}
+
+extern "C" int tomo_ctx_destroy(tomo_ctx *c)
+{
+    if (!c) return TOMO_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->comm) ncclCommDestroy(c->comm);
+    for (auto &p : c->pending) { c->ev_pool.push_back(p.e0); c->ev_pool.push_back(p.e1); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->d_volpad) (void)hipFree(c->d_volpad);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->d_red) (void)hipFree(c->d_red);
+    if (c->h_red) (void)hipHostFree(c->h_red);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return TOMO_OK;
+}
+
+extern "C" int tomo_device_name(tomo_ctx *ctx, char *buf, size_t n)
+{
+    if (!ctx || !buf || !n) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
+    hipDeviceProp_t p;
+    TOMO_HIP(ctx, hipGetDeviceProperties(&p, ctx->device));
+    snprintf(buf, n, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return TOMO_OK;
+}
+
+extern "C" int tomo_malloc(tomo_ctx *ctx, size_t bytes, void **d_ptr)
+{
+    if (!ctx || !d_ptr) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
+    TOMO_HIP(ctx, hipSetDevice(ctx->device));
+    TOMO_HIP(ctx, hipMalloc(d_ptr, bytes ? bytes : 4));
+    return TOMO_OK;
+}
+
+extern "C" int tomo_free(tomo_ctx *ctx, void *d_ptr)
+{
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    if (!d_ptr) return TOMO_OK;
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    TOMO_HIP(ctx, hipFree(d_ptr));
+    return TOMO_OK;
+}
+
+extern "C" int tomo_memcpy_h2d(tomo_ctx *ctx, void *d, const void *h, size_t bytes)
+{
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    TOMO_HIP(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // caller may reuse h immediately
+    return TOMO_OK;
+}
+
+extern "C" int tomo_memcpy_d2h(tomo_ctx *ctx, void *h, const void *d, size_t bytes)
+{
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    TOMO_HIP(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TOMO_OK;
+}
+
+extern "C" int tomo_memcpy_d2d(tomo_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    TOMO_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return TOMO_OK;
+}
+
+extern "C" int tomo_memset0(tomo_ctx *ctx, void *d, size_t bytes)
+{
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    TOMO_HIP(ctx, hipMemsetAsync(d, 0, bytes, ctx->stream));
+    return TOMO_OK;
+}
+
+extern "C" int tomo_sync(tomo_ctx *ctx)
+{
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TOMO_OK;
+}
+
+extern "C" int tomo_set_option(tomo_ctx *ctx, const char *key, int value)
+{
+    if (!ctx || !key) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
+    if (!strcmp(key, "fwd_variant")) ctx->fwd_variant = value;
+    else if (!strcmp(key, "adj_variant")) ctx->adj_variant = value;
+    else if (!strcmp(key, "adj_batch")) ctx->adj_batch = value;
+    else return tomo_fail(ctx, TOMO_ERR_ARG, std::string("unknown option ") + key);
+    return TOMO_OK;
+}
+
+int tomo_ensure_stage(tomo_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->stage_bytes) return TOMO_OK;
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    ctx->d_stage = ctx->h_stage = nullptr;
+    ctx->stage_bytes = 0;
+    size_t cap = std::max<size_t>(bytes, 1 << 16);
+    TOMO_HIP(ctx, hipMalloc(&ctx->d_stage, cap));
+    TOMO_HIP(ctx, hipHostMalloc(&ctx->h_stage, cap, hipHostMallocDefault));
+    ctx->stage_bytes = cap;
+    return TOMO_OK;
+}
+
+int tomo_ensure_red(tomo_ctx *ctx, size_t n)
+{
+    if (n <= ctx->red_cap) return TOMO_OK;
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_red) (void)hipFree(ctx->d_red);
+    if (ctx->h_red) (void)hipHostFree(ctx->h_red);
+    ctx->d_red = ctx->h_red = nullptr;
+    ctx->red_cap = 0;
+    size_t cap = std::max<size_t>(n, 4096);
+    TOMO_HIP(ctx, hipMalloc((void **)&ctx->d_red, cap * sizeof(double)));
+    TOMO_HIP(ctx, hipHostMalloc((void **)&ctx->h_red, cap * sizeof(double), hipHostMallocDefault));
+    ctx->red_cap = cap;
+    return TOMO_OK;
+}
+
+extern "C" int tomo_set_geometry(tomo_ctx *ctx, const tomo_geom *g)
+{
+    if (!ctx || !g) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
+    if (g->nx < 1 || g->ny < 1 || g->nz < 1 || g->ndx < 1 || g->ndz < 1 || !(g->step > 0.0) || !(g->det_y > g->src_y))
+        return tomo_fail(ctx, TOMO_ERR_ARG, "set_geometry: non-positive shape/step or det_y <= src_y");
+    TomoGeomC c{};
+    c.nx = g->nx; c.ny = g->ny; c.nz = g->nz; c.ndx = g->ndx; c.ndz = g->ndz;
+    c.nxp = g->nx + 2 * TOMO_HALO; c.nyp = g->ny + 2 * TOMO_HALO; c.nzp = g->nz + 2 * TOMO_HALO;
+    for (int a = 0; a < 3; ++a) c.org[a] = g->vox_origin[a];
+    c.det_x0 = g->det_x0; c.det_z0 = g->det_z0; c.det_dx = g->det_dx; c.det_dz = g->det_dz;
+    c.src_y = g->src_y; c.det_y = g->det_y; c.step = g->step;
+    size_t pe = (size_t)c.nxp * c.nyp * c.nzp;
+    if (pe >= ((size_t)1 << 31)) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "set_geometry: padded volume exceeds 2^31 voxels");
+    TOMO_HIP(ctx, hipSetDevice(ctx->device));
+    if (pe != ctx->volpad_elems) {
+        TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_volpad) (void)hipFree(ctx->d_volpad);
+        ctx->d_volpad = nullptr;
+        ctx->volpad_elems = 0;
+        TOMO_HIP(ctx, hipMalloc((void **)&ctx->d_volpad, pe * sizeof(float)));
+        ctx->volpad_elems = pe;
+    }
+    ctx->halo_dirty = true;
+    ctx->g = c;
+    for (int a = 0; a < 3; ++a) ctx->vox_pitch[a] = g->vox_pitch[a];
+    ctx->has_geom = true;
+    return TOMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// timing / profiling
+// ------------------------------------------------------------------------------------------------
+static hipEvent_t prof_event(tomo_ctx *ctx)
+{
+    if (!ctx->ev_pool.empty()) { hipEvent_t e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void tomo_prof_begin(tomo_ctx *ctx, const char *name)
+{
+    if (!ctx->profile_on) return;
+    ProfPending p;
+    p.name = name;
+    p.e0 = prof_event(ctx);
+    p.e1 = prof_event(ctx);
+    (void)hipEventRecord(p.e0, ctx->stream);
+    ctx->pending.push_back(p);
+}
+
+void tomo_prof_end(tomo_ctx *ctx)
+{
+    if (!ctx->profile_on || ctx->pending.empty()) return;
+    (void)hipEventRecord(ctx->pending.back().e1, ctx->stream);
+}
+
+static void prof_drain(tomo_ctx *ctx)
+{
+    if (ctx->pending.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            ProfRec &r = ctx->prof[p.name];
+            r.n += 1;
+            r.ms += ms;
+        }
+        ctx->ev_pool.push_back(p.e0);
+        ctx->ev_pool.push_back(p.e1);
+    }
+    ctx->pending.clear();
+}
+
+extern "C" int tomo_timer_start(tomo_ctx *ctx)
+{
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    TOMO_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return TOMO_OK;
+}
+
+extern "C" int tomo_timer_stop(tomo_ctx *ctx, float *ms)
+{
+    if (!ctx || !ms) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
+    TOMO_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    TOMO_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    TOMO_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return TOMO_OK;
+}
+
+extern "C" int tomo_profile_enable(tomo_ctx *ctx, int on)
+{
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    if (!on) prof_drain(ctx);
+    ctx->profile_on = on != 0;
+    return TOMO_OK;
+}
+
+extern "C" int tomo_profile_reset(tomo_ctx *ctx)
+{
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    prof_drain(ctx);
+    ctx->prof.clear();
+    return TOMO_OK;
+}
+
+extern "C" int tomo_profile_get(tomo_ctx *ctx, const char *kernel, int64_t *n, double *ms)
+{
+    if (!ctx || !kernel) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
+    prof_drain(ctx);
+    auto it = ctx->prof.find(kernel);
+    if (n) *n = it == ctx->prof.end() ? 0 : it->second.n;
+    if (ms) *ms = it == ctx->prof.end() ? 0.0 : it->second.ms;
+    return TOMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// solver vector kernels: HBM-streaming, coalesced dword grid-stride loops, <= 2048 work-groups
+// (they move ~0.6 % of a SIRT iteration's bytes: recon/sirt.py:60-73 vs :59,61).
+// Reductions: wave shuffle -> LDS -> one double atomic per work-group.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void block_atomic_sum(double v, double *dst)
+{
+    __shared__ double sh[4];
+    v = wave_sum_f64(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = sh[0] + sh[1] + sh[2] + sh[3];
+        atomicAdd(dst, s);
+    }
+}
+
+enum VecOp { VOP_RECIP_STRICT, VOP_RECIP_THRESH, VOP_FILL, VOP_AXPY, VOP_XPAY, VOP_SUB, VOP_MUL };
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_vec(float *__restrict__ y, const float *__restrict__ a, const float *__restrict__ b,
+                                             float s, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (OP == VOP_RECIP_STRICT) { float v = y[i]; y[i] = (v == 0.f) ? 0.f : 1.f / v; }      // recon/sirt.py:37-40 (x -> inf -> 1/inf = 0)
+        else if (OP == VOP_RECIP_THRESH) { float v = y[i]; y[i] = (v < s) ? 0.f : 1.f / v; }     // recon/sirt_mpi.py:69-72
+        else if (OP == VOP_FILL) y[i] = s;
+        else if (OP == VOP_AXPY) y[i] = fmaf(s, a[i], y[i]);
+        else if (OP == VOP_XPAY) y[i] = fmaf(s, y[i], a[i]);
+        else if (OP == VOP_SUB) y[i] = a[i] - b[i];
+        else if (OP == VOP_MUL) y[i] *= a[i];
+    }
+}
+
+static inline int vec_grid(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 2048); }
+
+#define VEC_CHECK(ctx, n)                                                  \
+    do {                                                                   \
+        if (!(ctx)) return tomo_fail(nullptr, TOMO_ERR_ARG, "null ctx");   \
+        if ((n) < 0) return tomo_fail((ctx), TOMO_ERR_ARG, "negative n");  \
+        if ((n) == 0) return TOMO_OK;                                      \
+    } while (0)
+
+extern "C" int tomo_vec_recip_guard(tomo_ctx *ctx, float *v, int64_t n, float thresh, int strict_zero)
+{
+    VEC_CHECK(ctx, n);
+    if (strict_zero) TOMO_LAUNCH(ctx, "k_vec", k_vec<VOP_RECIP_STRICT>, dim3(vec_grid(n)), dim3(256), 0, v, nullptr, nullptr, 0.f, n);
+    else TOMO_LAUNCH(ctx, "k_vec", k_vec<VOP_RECIP_THRESH>, dim3(vec_grid(n)), dim3(256), 0, v, nullptr, nullptr, thresh, n);
+    return TOMO_OK;
+}
+extern "C" int tomo_vec_fill(tomo_ctx *ctx, float *v, int64_t n, float value)
+{
+    VEC_CHECK(ctx, n);
+    TOMO_LAUNCH(ctx, "k_vec", k_vec<VOP_FILL>, dim3(vec_grid(n)), dim3(256), 0, v, nullptr, nullptr, value, n);
+    return TOMO_OK;
+}
+extern "C" int tomo_vec_axpy(tomo_ctx *ctx, float *y, const float *x, float a, int64_t n)
+{
+    VEC_CHECK(ctx, n);
+    TOMO_LAUNCH(ctx, "k_vec", k_vec<VOP_AXPY>, dim3(vec_grid(n)), dim3(256), 0, y, x, nullptr, a, n);
+    return TOMO_OK;
+}
+extern "C" int tomo_vec_xpay(tomo_ctx *ctx, float *y, const float *x, float a, int64_t n)
+{
+    VEC_CHECK(ctx, n);
+    TOMO_LAUNCH(ctx, "k_vec", k_vec<VOP_XPAY>, dim3(vec_grid(n)), dim3(256), 0, y, x, nullptr, a, n);
+    return TOMO_OK;
+}
+extern "C" int tomo_vec_sub(tomo_ctx *ctx, float *out, const float *a, const float *b, int64_t n)
+{
+    VEC_CHECK(ctx, n);
+    TOMO_LAUNCH(ctx, "k_vec", k_vec<VOP_SUB>, dim3(vec_grid(n)), dim3(256), 0, out, a, b, 0.f, n);
+    return TOMO_OK;
+}
+extern "C" int tomo_vec_mul(tomo_ctx *ctx, float *y, const float *x, int64_t n)
+{
+    VEC_CHECK(ctx, n);
+    TOMO_LAUNCH(ctx, "k_vec", k_vec<VOP_MUL>, dim3(vec_grid(n)), dim3(256), 0, y, x, nullptr, 0.f, n);
+    return TOMO_OK;
+}
+
+// out = w*(b-ax), sumsq += (b-ax)^2          recon/sirt.py:60-61,69
+__global__ __launch_bounds__(256) void k_residual_scale(const float *__restrict__ b, const float *__restrict__ ax,
+                                                        const float *__restrict__ w, float *__restrict__ out, int64_t n, double *sumsq)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float r = b[i] - ax[i];
+        acc += (double)r * (double)r;
+        out[i] = w ? w[i] * r : r;
+    }
+    block_atomic_sum(acc, sumsq);
+}
+
+// rec += v*bp ; rec = max(rec,0) if positivity ; err += (gt-rec)^2     recon/sirt.py:63-67,73
+__global__ __launch_bounds__(256) void k_update(float *__restrict__ rec, const float *__restrict__ bp, const float *__restrict__ v,
+                                                int64_t n, int positivity, const float *__restrict__ gt, double *sumsq)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float r = rec[i] + (v ? bp[i] * v[i] : bp[i]);
+        if (positivity && r < 0.f) r = 0.f;
+        rec[i] = r;
+        if (gt) { float e = gt[i] - r; acc += (double)e * (double)e; }
+    }
+    if (gt) block_atomic_sum(acc, sumsq);
+}
+
+__global__ __launch_bounds__(256) void k_dot(const float *__restrict__ a, const float *__restrict__ b, int64_t n, int diff, double *out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (diff) { float e = a[i] - b[i]; acc += (double)e * (double)e; }
+        else acc += (double)a[i] * (double)b[i];
+    }
+    block_atomic_sum(acc, out);
+}
+
+static int red_fetch(tomo_ctx *ctx, double *h_out)
+{
+    TOMO_HIP(ctx, hipMemcpyAsync(ctx->h_red, ctx->d_red, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *h_out = ctx->h_red[0];
+    return TOMO_OK;
+}
+
+extern "C" int tomo_vec_residual_scale(tomo_ctx *ctx, const float *b, const float *ax, const float *w, float *out, int64_t n,
+                                       double *h_sumsq)
+{
+    VEC_CHECK(ctx, n);
+    int rc = tomo_ensure_red(ctx, 8);
+    if (rc) return rc;
+    TOMO_HIP(ctx, hipMemsetAsync(ctx->d_red, 0, sizeof(double), ctx->stream));
+    TOMO_LAUNCH(ctx, "k_residual_scale", k_residual_scale, dim3(vec_grid(n)), dim3(256), 0, b, ax, w, out, n, ctx->d_red);
+    return h_sumsq ? red_fetch(ctx, h_sumsq) : TOMO_OK;
+}
+
+extern "C" int tomo_vec_update(tomo_ctx *ctx, float *rec, const float *bp, const float *v, int64_t n, int positivity,
+                               const float *gt, double *h_sumsq_err)
+{
+    VEC_CHECK(ctx, n);
+    int rc = tomo_ensure_red(ctx, 8);
+    if (rc) return rc;
+    TOMO_HIP(ctx, hipMemsetAsync(ctx->d_red, 0, sizeof(double), ctx->stream));
+    TOMO_LAUNCH(ctx, "k_update", k_update, dim3(vec_grid(n)), dim3(256), 0, rec, bp, v, n, positivity, gt, ctx->d_red);
+    return (gt && h_sumsq_err) ? red_fetch(ctx, h_sumsq_err) : TOMO_OK;
+}
+
+extern "C" int tomo_vec_dot(tomo_ctx *ctx, const float *a, const float *b, int64_t n, double *h_dot)
+{
+    if (!h_dot) return tomo_fail(ctx, TOMO_ERR_ARG, "null out");
+    *h_dot = 0.0;
+    VEC_CHECK(ctx, n);
+    int rc = tomo_ensure_red(ctx, 8);
+    if (rc) return rc;
+    TOMO_HIP(ctx, hipMemsetAsync(ctx->d_red, 0, sizeof(double), ctx->stream));
+    TOMO_LAUNCH(ctx, "k_dot", k_dot, dim3(vec_grid(n)), dim3(256), 0, a, b, n, 0, ctx->d_red);
+    return red_fetch(ctx, h_dot);
+}
+
+extern "C" int tomo_vec_diff_sumsq(tomo_ctx *ctx, const float *a, const float *b, int64_t n, double *h_sumsq)
+{
+    if (!h_sumsq) return tomo_fail(ctx, TOMO_ERR_ARG, "null out");
+    *h_sumsq = 0.0;
+    VEC_CHECK(ctx, n);
+    int rc = tomo_ensure_red(ctx, 8);
+    if (rc) return rc;
+    TOMO_HIP(ctx, hipMemsetAsync(ctx->d_red, 0, sizeof(double), ctx->stream));
+    TOMO_LAUNCH(ctx, "k_dot", k_dot, dim3(vec_grid(n)), dim3(256), 0, a, b, n, 1, ctx->d_red);
+    return red_fetch(ctx, h_sumsq);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCCL over xGMI: one process per GPU; replaces mpi4py Allreduce (recon/sirt_mpi.py:68,103,110;
+// recon/cgls_mpi.py:55,75-76,98,107).
+// ------------------------------------------------------------------------------------------------
+#define TOMO_NCCL(ctx, call)                                                                          \
+    do {                                                                                              \
+        ncclResult_t r_ = (call);                                                                     \
+        if (r_ != ncclSuccess)                                                                        \
+            return tomo_fail((ctx), TOMO_ERR_RCCL, std::string(#call) + ": " + ncclGetErrorString(r_)); \
+    } while (0)
+
+extern "C" int tomo_comm_get_unique_id(void *h_id128)
+{
+    if (!h_id128) return tomo_fail(nullptr, TOMO_ERR_ARG, "null id");
+    static_assert(sizeof(ncclUniqueId) <= TOMO_COMM_ID_BYTES, "id size");
+    ncclUniqueId id;
+    TOMO_NCCL(nullptr, ncclGetUniqueId(&id));
+    memset(h_id128, 0, TOMO_COMM_ID_BYTES);
+    memcpy(h_id128, &id, sizeof(id));
+    return TOMO_OK;
+}
+
+extern "C" int tomo_comm_init(tomo_ctx *ctx, const void *h_id128, int n_ranks, int rank)
+{
+    if (!ctx || !h_id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
+    if (ctx->comm) return tomo_fail(ctx, TOMO_ERR_STATE, "comm already initialised");
+    TOMO_HIP(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, h_id128, sizeof(id));
+    TOMO_NCCL(ctx, ncclCommInitRank(&ctx->comm, n_ranks, id, rank));
+    ctx->n_ranks = n_ranks;
+    ctx->rank = rank;
+    return TOMO_OK;
+}
+
+extern "C" int tomo_comm_destroy(tomo_ctx *ctx)
+{
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    if (ctx->comm) {
+        (void)hipStreamSynchronize(ctx->stream);
+        ncclCommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+    }
+    ctx->n_ranks = 1;
+    ctx->rank = 0;
+    return TOMO_OK;
+}
+
+extern "C" int tomo_allreduce_sum_f32(tomo_ctx *ctx, float *d_buf, int64_t n)
+{
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    if (!ctx->comm) return ctx->n_ranks == 1 ? TOMO_OK : tomo_fail(ctx, TOMO_ERR_STATE, "comm not initialised");
+    tomo_prof_begin(ctx, "allreduce_f32");
+    ncclResult_t r = ncclAllReduce(d_buf, d_buf, (size_t)n, ncclFloat32, ncclSum, ctx->comm, ctx->stream);
+    tomo_prof_end(ctx);
+    if (r != ncclSuccess) return tomo_fail(ctx, TOMO_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    return TOMO_OK;
+}
+
+static int host_allreduce_f64(tomo_ctx *ctx, double *h_vals, int n, ncclRedOp_t op)
+{
+    if (!ctx || !h_vals || n < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
+    if (!ctx->comm || n == 0) return TOMO_OK;
+    int rc = tomo_ensure_red(ctx, (size_t)n + 8);
+    if (rc) return rc;
+    memcpy(ctx->h_red + 8, h_vals, sizeof(double) * n);
+    TOMO_HIP(ctx, hipMemcpyAsync(ctx->d_red + 8, ctx->h_red + 8, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    TOMO_NCCL(ctx, ncclAllReduce(ctx->d_red + 8, ctx->d_red + 8, (size_t)n, ncclFloat64, op, ctx->comm, ctx->stream));
+    TOMO_HIP(ctx, hipMemcpyAsync(ctx->h_red + 8, ctx->d_red + 8, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(h_vals, ctx->h_red + 8, sizeof(double) * n);
+    return TOMO_OK;
+}
+
+extern "C" int tomo_allreduce_sum_f64_host(tomo_ctx *ctx, double *h_vals, int n) { return host_allreduce_f64(ctx, h_vals, n, ncclSum); }
+extern "C" int tomo_allreduce_max_f64_host(tomo_ctx *ctx, double *h_vals, int n) { return host_allreduce_f64(ctx, h_vals, n, ncclMax); }

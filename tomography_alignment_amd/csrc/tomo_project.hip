@@ -1,0 +1,546 @@
+// tomo_project.hip -- gfx950 kernels of the ray-driven projection hot path.
+//
+// Work decomposition (all kernels): one ray per work-item, the 64 lanes of a wavefront run along
+// detector-z == the memory-fastest volume axis (src/ray_wt_grad.f90:38), so every corner row a wave
+// touches is one contiguous ~256-B run; the 4 waves of a 256-thread work-group take 4 adjacent
+// detector-x rays, whose corner rows overlap in the CU's L1.  No MFMA: this is gather/scatter ray
+// marching, bounded by L1/LDS/HBM traffic, not a dense contraction.
+//
+// Kernels                              replaces (reference)
+//   k_pad / k_unpad                    -- (zero-halo staging of the volume; removes the 8 per-corner
+//                                         bounds tests of src/ray_wt_grad.f90:35-89 from the loop)
+//   k_fwd_v1 / k_fwd_v2                A.x : recon/sirt.py:59 ; src/forward_projection.f90:1-68
+//   k_adj_v1                           A^T.y : recon/sirt.py:61 (global float atomics, reference form)
+//   k_bp_voxel                         src/back_projection.f90:1-34
+//   k_proj_grad<FUSED>                 src/ray_wt_grad.f90:95-223 ; src/projection_gradient.f90:1-79 ;
+//                                      utilities/alignment_functions.py:16-37,124,146 (FUSED)
+#include <limits.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "tomo_ctx.h"
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers (64 lanes)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int64_t readfirstlane_i64(int64_t v)
+{
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// ------------------------------------------------------------------------------------------------
+// zero-halo staging
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pad(const float *__restrict__ vol, float *__restrict__ vp, TomoGeomC g)
+{
+    const int row = blockIdx.x;            // ix*ny + iy
+    const int ix = row / g.ny, iy = row - ix * g.ny;
+    const float *src = vol + (size_t)row * g.nz;
+    float *dst = vp + ((size_t)(ix + TOMO_HALO) * g.nyp + (iy + TOMO_HALO)) * g.nzp + TOMO_HALO;
+    for (int z = threadIdx.x; z < g.nz; z += blockDim.x) dst[z] = src[z];
+}
+
+__global__ __launch_bounds__(256) void k_unpad(float *__restrict__ vol, const float *__restrict__ vp, TomoGeomC g, int accumulate)
+{
+    const int row = blockIdx.x;
+    const int ix = row / g.ny, iy = row - ix * g.ny;
+    float *dst = vol + (size_t)row * g.nz;
+    const float *src = vp + ((size_t)(ix + TOMO_HALO) * g.nyp + (iy + TOMO_HALO)) * g.nzp + TOMO_HALO;
+    if (accumulate)
+        for (int z = threadIdx.x; z < g.nz; z += blockDim.x) dst[z] += src[z];
+    else
+        for (int z = threadIdx.x; z < g.nz; z += blockDim.x) dst[z] = src[z];
+}
+
+static int stage_volume(tomo_ctx *ctx, const float *d_vol)
+{
+    const TomoGeomC &g = ctx->g;
+    if (ctx->halo_dirty) {
+        TOMO_HIP(ctx, hipMemsetAsync(ctx->d_volpad, 0, ctx->volpad_elems * sizeof(float), ctx->stream));
+        ctx->halo_dirty = false;
+    }
+    TOMO_LAUNCH(ctx, "k_pad", k_pad, dim3(g.nx * g.ny), dim3(256), 0, d_vol, ctx->d_volpad, g);
+    return TOMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-ray set-up shared by the ray-driven kernels
+// ------------------------------------------------------------------------------------------------
+struct RayCtx {
+    double b[3], d[3];
+    int j0, j1;
+};
+
+__device__ __forceinline__ void ray_setup(const ProjC &c, const TomoGeomC &g, int ix, int iz, bool valid, RayCtx &r)
+{
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        r.b[a] = c.p0[a] + (double)ix * c.u[a] + (double)iz * c.w[a];
+        r.d[a] = c.d[a];
+    }
+    tomo_ray_range(r.b, r.d, c.n, g.nx, g.ny, g.nz, r.j0, r.j1);
+    if (!valid) r.j0 = r.j1 = 0;
+}
+
+// trilinear value from the 8 loaded corners: v000 + wz*(v001-v000) ... == sum rec*wx*wy*wz of
+// src/ray_wt_grad.f90:143-145 with wf = 1-wc (utilities/ray_voxel_utilities.py:98-99)
+__device__ __forceinline__ float trilerp(float v000, float v001, float v010, float v011, float v100, float v101, float v110,
+                                         float v111, float wx, float wy, float wz)
+{
+    float c00 = fmaf(wz, v001 - v000, v000);
+    float c01 = fmaf(wz, v011 - v010, v010);
+    float c10 = fmaf(wz, v101 - v100, v100);
+    float c11 = fmaf(wz, v111 - v110, v110);
+    float e0 = fmaf(wy, c01 - c00, c00);
+    float e1 = fmaf(wy, c11 - c10, c10);
+    return fmaf(wx, e1 - e0, e0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward projection, variant 1: plain 64-bit indexing (reference form of the algorithm)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwd_v1(const ProjC *__restrict__ pcs, const float *__restrict__ vp,
+                                                float *__restrict__ proj, TomoGeomC g)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int iz = blockIdx.x * 64 + lane, ix = blockIdx.y * 4 + wv, ip = blockIdx.z;
+    if (ix >= g.ndx || iz >= g.ndz) return;
+    const ProjC &c = pcs[ip];
+    RayCtx r;
+    ray_setup(c, g, ix, iz, true, r);
+    const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
+    const int64_t sy = g.nzp, sx = (int64_t)g.nyp * g.nzp;
+    double total = 0.0;
+    for (int jb = r.j0; jb < r.j1; jb += TOMO_JB) {
+        int ia[3];
+        float f0[3];
+        tomo_block_anchor(r.b, r.d, jb, ia, f0);
+        const float *base = vp + ((int64_t)(ia[0] + TOMO_HALO) * sx + (int64_t)(ia[1] + TOMO_HALO) * sy + (ia[2] + TOMO_HALO));
+        const int cnt = min(TOMO_JB, r.j1 - jb);
+        float acc = 0.f;
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float t = (float)jj;
+            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
+            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+            const float *q = base + ((int64_t)(int)fx * sx + (int64_t)(int)fy * sy + (int)fz);
+            acc += trilerp(q[0], q[1], q[sy], q[sy + 1], q[sx], q[sx + 1], q[sx + sy], q[sx + sy + 1], x - fx, y - fy, z - fz);
+        }
+        total += (double)acc;
+    }
+    proj[((size_t)ip * g.ndx + ix) * g.ndz + iz] = (float)total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward projection, variant 2: wave-uniform 64-bit block base in SGPRs + one unsigned 32-bit byte
+// offset per lane shared by all 8 corner loads (global_load_dword v, v_off, s[base], offset:0|4).
+// The block loop runs over the wave-uniform union of the lanes' sample ranges so the cross-lane
+// minimum is taken with every lane active.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwd_v2(const ProjC *__restrict__ pcs, const float *__restrict__ vp,
+                                                float *__restrict__ proj, TomoGeomC g)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ix = blockIdx.y * 4 + wv, ip = blockIdx.z;
+    if (ix >= g.ndx) return;                       // wave-uniform exit
+    int iz = blockIdx.x * 64 + lane;
+    const bool valid = iz < g.ndz;
+    if (!valid) iz = g.ndz - 1;                    // keep the lane's arithmetic in range; it contributes nothing
+    const ProjC &c = pcs[ip];
+    RayCtx r;
+    ray_setup(c, g, ix, iz, valid, r);
+    const bool nonempty = r.j1 > r.j0;
+    const int J0 = __builtin_amdgcn_readfirstlane(wave_min_i32(nonempty ? r.j0 : INT_MAX));
+    const int J1 = __builtin_amdgcn_readfirstlane(wave_max_i32(nonempty ? r.j1 : 0));
+    const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
+    const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;
+    double total = 0.0;
+    for (int jb = J0; jb < J1; jb += TOMO_JB) {
+        int ia[3];
+        float f0[3];
+        tomo_block_anchor(r.b, r.d, jb, ia, f0);
+        const int64_t lin = ((int64_t)(ia[0] + TOMO_HALO) * g.nyp + (ia[1] + TOMO_HALO)) * g.nzp + (ia[2] + TOMO_HALO);
+        const int64_t lin0 = readfirstlane_i64(lin);
+        const int delta = (int)(lin - lin0);       // neighbouring rays at the same j: a few rows apart
+        const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(delta));
+        const char *sb00 = (const char *)(vp + (lin0 + m));
+        const char *sb01 = sb00 + sy4;
+        const char *sb10 = sb00 + sx4;
+        const char *sb11 = sb10 + sy4;
+        const uint32_t off0 = (uint32_t)(delta - m) * 4u;
+        const int lo = max(r.j0, jb) - jb, hi = min(r.j1, jb + TOMO_JB) - jb;
+        float acc = 0.f;
+        for (int jj = lo; jj < hi; ++jj) {
+            const float t = (float)jj;
+            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
+            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+            const uint32_t vo = off0 + __umul24((uint32_t)(int)fx, sx4) + __umul24((uint32_t)(int)fy, sy4) + ((uint32_t)(int)fz << 2);
+            const float v000 = *(const float *)(sb00 + vo), v001 = *(const float *)(sb00 + vo + 4);
+            const float v010 = *(const float *)(sb01 + vo), v011 = *(const float *)(sb01 + vo + 4);
+            const float v100 = *(const float *)(sb10 + vo), v101 = *(const float *)(sb10 + vo + 4);
+            const float v110 = *(const float *)(sb11 + vo), v111 = *(const float *)(sb11 + vo + 4);
+            acc += trilerp(v000, v001, v010, v011, v100, v101, v110, v111, x - fx, y - fy, z - fz);
+        }
+        total += (double)acc;
+    }
+    if (valid) proj[((size_t)ip * g.ndx + ix) * g.ndz + iz] = (float)total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// adjoint, variant 1: the same traversal scattering w*y with global float atomics into the padded
+// scratch volume (halo swallows the out-of-bounds corners).  Atomic-rate bound (~1.3 TB/s of added
+// bytes, MI355X_MICROARCH 'Global float atomics'): kept as the simple reference form for parity.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adj_v1(const ProjC *__restrict__ pcs, const float *__restrict__ proj,
+                                                float *__restrict__ vp, TomoGeomC g)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int iz = blockIdx.x * 64 + lane, ix = blockIdx.y * 4 + wv, ip = blockIdx.z;
+    if (ix >= g.ndx || iz >= g.ndz) return;
+    const ProjC &c = pcs[ip];
+    RayCtx r;
+    ray_setup(c, g, ix, iz, true, r);
+    const float yv = proj[((size_t)ip * g.ndx + ix) * g.ndz + iz];
+    const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
+    const int64_t sy = g.nzp, sx = (int64_t)g.nyp * g.nzp;
+    for (int jb = r.j0; jb < r.j1; jb += TOMO_JB) {
+        int ia[3];
+        float f0[3];
+        tomo_block_anchor(r.b, r.d, jb, ia, f0);
+        float *base = vp + ((int64_t)(ia[0] + TOMO_HALO) * sx + (int64_t)(ia[1] + TOMO_HALO) * sy + (ia[2] + TOMO_HALO));
+        const int cnt = min(TOMO_JB, r.j1 - jb);
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float t = (float)jj;
+            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
+            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+            const float wcx = x - fx, wcy = y - fy, wcz = z - fz;
+            const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
+            float *q = base + ((int64_t)(int)fx * sx + (int64_t)(int)fy * sy + (int)fz);
+            const float a0 = yv * wfx, a1 = yv * wcx;
+            const float b00 = a0 * wfy, b01 = a0 * wcy, b10 = a1 * wfy, b11 = a1 * wcy;
+            atomicAdd(q, b00 * wfz);
+            atomicAdd(q + 1, b00 * wcz);
+            atomicAdd(q + sy, b01 * wfz);
+            atomicAdd(q + sy + 1, b01 * wcz);
+            atomicAdd(q + sx, b10 * wfz);
+            atomicAdd(q + sx + 1, b10 * wcz);
+            atomicAdd(q + sx + sy, b11 * wfz);
+            atomicAdd(q + sx + sy + 1, b11 * wcz);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// voxel-driven bilinear back-projector (src/back_projection.f90:25-32): one voxel per work-item,
+// lanes along z, loop over projections with the accumulator in a register; the voxel centre is
+// transformed on the fly (the reference re-reads a (3,n_vox) voxel_centers array per projection).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bp_voxel(const BpC *__restrict__ cs, int n_proj, const float *__restrict__ det,
+                                                  float *__restrict__ vol, TomoGeomC g)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int iz = blockIdx.x * 64 + lane, iy = blockIdx.y * 4 + wv, ix = blockIdx.z;
+    if (iy >= g.ny || iz >= g.nz) return;
+    const size_t img = (size_t)g.ndx * g.ndz;
+    float acc = 0.f;
+    for (int ip = 0; ip < n_proj; ++ip) {
+        const BpC c = cs[ip];
+        const double u = c.u0 + ix * c.ux + iy * c.uy + iz * c.uz;
+        const double v = c.v0 + ix * c.vx + iy * c.vy + iz * c.vz;
+        if (!(u >= -1.0 && u < (double)g.ndx && v >= -1.0 && v < (double)g.ndz)) continue;
+        const double fu = floor(u), fv = floor(v);
+        const int fx = (int)fu, fz = (int)fv;
+        const float ax = (float)(u - fu), az = (float)(v - fv);      // external_back_projection.f90:47-48
+        const float *im = det + (size_t)ip * img;
+        const bool x0 = fx >= 0, x1 = fx + 1 < g.ndx, z0 = fz >= 0, z1 = fz + 1 < g.ndz;
+        float s = 0.f;                                                 // :54-65, per-pixel bounds tests
+        if (x0 && z0) s += im[(size_t)fx * g.ndz + fz] * (1.f - ax) * (1.f - az);
+        if (x1 && z0) s += im[(size_t)(fx + 1) * g.ndz + fz] * ax * (1.f - az);
+        if (x0 && z1) s += im[(size_t)fx * g.ndz + fz + 1] * (1.f - ax) * az;
+        if (x1 && z1) s += im[(size_t)(fx + 1) * g.ndz + fz + 1] * ax * az;
+        acc += s;                                                      // back_projection.f90:31
+    }
+    vol[((size_t)ix * g.ny + iy) * g.nz + iz] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// projection + 6-DoF pose gradient.  Per sample only the interpolant's spatial gradient is formed
+// (3 values); S0 = sum_j grad_j and S1 = sum_j sf_j*grad_j are accumulated and the per-ray 9x3 pose
+// Jacobian is applied once (same algebra as src/ray_wt_grad.f90:136-149).
+// FUSED: multiply by the residual and reduce to 7 numbers per projection.
+// ------------------------------------------------------------------------------------------------
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_proj_grad(const ProjC *__restrict__ pcs, const GradC *__restrict__ gcs,
+                                                   const float *__restrict__ vp, float *__restrict__ proj,
+                                                   float *__restrict__ grad, const float *__restrict__ bvec,
+                                                   float *__restrict__ resid, double *__restrict__ red, TomoGeomC g,
+                                                   int row_order)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ix = blockIdx.y * 4 + wv, ip = blockIdx.z;
+    int iz = blockIdx.x * 64 + lane;
+    const bool valid = (ix < g.ndx) && (iz < g.ndz);
+    const int ixc = min(ix, g.ndx - 1);
+    if (iz >= g.ndz) iz = g.ndz - 1;
+    const ProjC &c = pcs[ip];
+    const GradC &gc = gcs[ip];
+    RayCtx r;
+    ray_setup(c, g, ixc, iz, valid, r);
+    const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
+    const int64_t sy = g.nzp, sx = (int64_t)g.nyp * g.nzp;
+    const float sfs = (float)(g.step / c.rlen);      // sf_j = (j*step)/|r_0|   ray_voxel_utilities.py:151
+    double val = 0.0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
+    for (int jb = r.j0; jb < r.j1; jb += TOMO_JB) {
+        int ia[3];
+        float f0[3];
+        tomo_block_anchor(r.b, r.d, jb, ia, f0);
+        const float *base = vp + ((int64_t)(ia[0] + TOMO_HALO) * sx + (int64_t)(ia[1] + TOMO_HALO) * sy + (ia[2] + TOMO_HALO));
+        const int cnt = min(TOMO_JB, r.j1 - jb);
+        float av = 0.f, a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float t = (float)jj;
+            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
+            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+            const float wx = x - fx, wy = y - fy, wz = z - fz;
+            const float *q = base + ((int64_t)(int)fx * sx + (int64_t)(int)fy * sy + (int)fz);
+            const float v000 = q[0], v001 = q[1], v010 = q[sy], v011 = q[sy + 1];
+            const float v100 = q[sx], v101 = q[sx + 1], v110 = q[sx + sy], v111 = q[sx + sy + 1];
+            const float d00 = v001 - v000, d01 = v011 - v010, d10 = v101 - v100, d11 = v111 - v110;
+            const float c00 = fmaf(wz, d00, v000), c01 = fmaf(wz, d01, v010), c10 = fmaf(wz, d10, v100), c11 = fmaf(wz, d11, v110);
+            const float dz0 = fmaf(wy, d01 - d00, d00), dz1 = fmaf(wy, d11 - d10, d10);
+            const float gz = fmaf(wx, dz1 - dz0, dz0);
+            const float dy0 = c01 - c00, dy1 = c11 - c10;
+            const float e0 = fmaf(wy, dy0, c00), e1 = fmaf(wy, dy1, c10);
+            const float gy = fmaf(wx, dy1 - dy0, dy0);
+            const float gx = e1 - e0;
+            av += fmaf(wx, gx, e0);
+            const float sf = (float)(jb + jj) * sfs;
+            a0x += gx; a0y += gy; a0z += gz;
+            a1x = fmaf(sf, gx, a1x); a1y = fmaf(sf, gy, a1y); a1z = fmaf(sf, gz, a1z);
+        }
+        val += (double)av;
+        s0[0] += (double)a0x; s0[1] += (double)a0y; s0[2] += (double)a0z;
+        s1[0] += (double)a1x; s1[1] += (double)a1y; s1[2] += (double)a1z;
+    }
+    // per-ray pose Jacobian (utilities/ray_voxel_utilities.py:38-49)
+    const double s[3] = {gc.s00[0] + ixc * gc.sdx, gc.s00[1], gc.s00[2] + iz * gc.sdz};
+    double qv[3], gk[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) qv[a] = gc.ry[a][0] * s[0] + gc.ry[a][1] * s[1] + gc.ry[a][2] * s[2] + gc.t[a];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gk[k] = gc.rzx[0][k] * s0[0] + gc.rzx[1][k] * s0[1] + gc.rzx[2][k] * s0[2];
+    gk[3] = gk[4] = gk[5] = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double d3 = gc.a3[a][0] * qv[0] + gc.a3[a][1] * qv[1] + gc.a3[a][2] * qv[2];
+        const double d4 = gc.a4[a][0] * qv[0] + gc.a4[a][1] * qv[1] + gc.a4[a][2] * qv[2];
+        const double d5 = gc.a5[a][0] * s[0] + gc.a5[a][1] * s[1] + gc.a5[a][2] * s[2];
+        gk[3] += d3 * s0[a] + gc.app[0][a] * s1[a];
+        gk[4] += d4 * s0[a] + gc.app[1][a] * s1[a];
+        gk[5] += d5 * s0[a] + gc.app[2][a] * s1[a];
+    }
+    const size_t n_det = (size_t)g.ndx * g.ndz;
+    const size_t ray = (size_t)ixc * g.ndz + iz;
+    if (!FUSED) {
+        if (valid) {
+            proj[ray] = (float)val;
+            if (row_order == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) grad[k * n_det + ray] = (float)gk[k];
+            } else {   // tx,ty,tz,alpha,beta,phi  (src/external_forward_projection.f90:56-69)
+                grad[0 * n_det + ray] = (float)gk[0]; grad[1 * n_det + ray] = (float)gk[1]; grad[2 * n_det + ray] = (float)gk[2];
+                grad[3 * n_det + ray] = (float)gk[4]; grad[4 * n_det + ray] = (float)gk[5]; grad[5 * n_det + ray] = (float)gk[3];
+            }
+        }
+    } else {
+        double part[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (valid) {
+            const float pv = (float)val;                                  // projection_operators.py:119 cast
+            const double res = (double)(bvec[(size_t)ip * n_det + ray] - pv);   // alignment_functions.py:23
+            if (resid) resid[(size_t)ip * n_det + ray] = (float)res;
+            part[0] = 0.5 * res * res;                                    // :124
+#pragma unroll
+            for (int k = 0; k < 6; ++k) part[1 + k] = -(double)(float)gk[k] * res;   // :35,146
+        }
+        __shared__ double sh[4][7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const double w = wave_sum_d(part[k]);
+            if (lane == 0) sh[wv][k] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x < 7) {
+            const int k = threadIdx.x;
+            atomicAdd(&red[(size_t)ip * 7 + k], sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int upload_projc(tomo_ctx *ctx, const double *h_poses, int n, bool with_grad, ProjC **d_pc, GradC **d_gc)
+{
+    const size_t pc_bytes = sizeof(ProjC) * (size_t)n;
+    const size_t gc_off = (pc_bytes + 255) & ~(size_t)255;
+    const size_t total = gc_off + (with_grad ? sizeof(GradC) * (size_t)n : 0);
+    // the staging buffer may still be in use by an earlier async launch: drain before rewriting it
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = tomo_ensure_stage(ctx, total);
+    if (rc) return rc;
+    ProjC *hp = (ProjC *)ctx->h_stage;
+    GradC *hg = (GradC *)((char *)ctx->h_stage + gc_off);
+    for (int i = 0; i < n; ++i) tomo_make_projc(ctx->g, h_poses + (size_t)i * TOMO_POSE_STRIDE, hp[i], with_grad ? &hg[i] : nullptr);
+    TOMO_HIP(ctx, hipMemcpyAsync(ctx->d_stage, ctx->h_stage, total, hipMemcpyHostToDevice, ctx->stream));
+    *d_pc = (ProjC *)ctx->d_stage;
+    if (d_gc) *d_gc = (GradC *)((char *)ctx->d_stage + gc_off);
+    return TOMO_OK;
+}
+
+static inline dim3 ray_grid(const TomoGeomC &g, int n_proj) { return dim3((g.ndz + 63) / 64, (g.ndx + 3) / 4, n_proj); }
+
+#define TOMO_MAX_GRID_Z 65535
+
+extern "C" int tomo_forward(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_vol, float *d_proj)
+{
+    TOMO_NEED_GEOM(ctx);
+    if (!h_poses || !d_vol || !d_proj || n_proj < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_forward: bad args");
+    if (n_proj == 0) return TOMO_OK;
+    const TomoGeomC &g = ctx->g;
+    int rc = stage_volume(ctx, d_vol);
+    if (rc) return rc;
+    const size_t n_det = (size_t)g.ndx * g.ndz;
+    for (int p0 = 0; p0 < n_proj; p0 += TOMO_MAX_GRID_Z) {
+        const int np = std::min(TOMO_MAX_GRID_Z, n_proj - p0);
+        ProjC *d_pc = nullptr;
+        rc = upload_projc(ctx, h_poses + (size_t)p0 * TOMO_POSE_STRIDE, np, false, &d_pc, nullptr);
+        if (rc) return rc;
+        float *out = d_proj + (size_t)p0 * n_det;
+        if (ctx->fwd_variant == 1)
+            TOMO_LAUNCH(ctx, "k_fwd_v1", k_fwd_v1, ray_grid(g, np), dim3(256), 0, d_pc, ctx->d_volpad, out, g);
+        else
+            TOMO_LAUNCH(ctx, "k_fwd_v2", k_fwd_v2, ray_grid(g, np), dim3(256), 0, d_pc, ctx->d_volpad, out, g);
+    }
+    return TOMO_OK;
+}
+
+extern "C" int tomo_adjoint(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_proj, float *d_vol, int accumulate)
+{
+    TOMO_NEED_GEOM(ctx);
+    if (!h_poses || !d_vol || !d_proj || n_proj < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_adjoint: bad args");
+    const TomoGeomC &g = ctx->g;
+    const size_t n_det = (size_t)g.ndx * g.ndz;
+    TOMO_HIP(ctx, hipMemsetAsync(ctx->d_volpad, 0, ctx->volpad_elems * sizeof(float), ctx->stream));
+    ctx->halo_dirty = true;   // the halo collects the out-of-bounds corners
+    for (int p0 = 0; p0 < n_proj; p0 += TOMO_MAX_GRID_Z) {
+        const int np = std::min(TOMO_MAX_GRID_Z, n_proj - p0);
+        ProjC *d_pc = nullptr;
+        int rc = upload_projc(ctx, h_poses + (size_t)p0 * TOMO_POSE_STRIDE, np, false, &d_pc, nullptr);
+        if (rc) return rc;
+        TOMO_LAUNCH(ctx, "k_adj_v1", k_adj_v1, ray_grid(g, np), dim3(256), 0, d_pc, d_proj + (size_t)p0 * n_det, ctx->d_volpad, g);
+    }
+    TOMO_LAUNCH(ctx, "k_unpad", k_unpad, dim3(g.nx * g.ny), dim3(256), 0, d_vol, ctx->d_volpad, g, accumulate);
+    return TOMO_OK;
+}
+
+extern "C" int tomo_backproject_voxel(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_det, float *d_vol)
+{
+    TOMO_NEED_GEOM(ctx);
+    if (!h_poses || !d_det || !d_vol || n_proj < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_backproject_voxel: bad args");
+    const TomoGeomC &g = ctx->g;
+    if (g.nx > TOMO_MAX_GRID_Z) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "tomo_backproject_voxel: nx > 65535");
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = tomo_ensure_stage(ctx, sizeof(BpC) * (size_t)std::max(n_proj, 1));
+    if (rc) return rc;
+    BpC *h = (BpC *)ctx->h_stage;
+    for (int i = 0; i < n_proj; ++i) {
+        const double *p = h_poses + (size_t)i * TOMO_POSE_STRIDE;
+        // x' = Ry(beta) (Rx(alpha) Rz(phi) c + t)            src/external_back_projection.f90:20-25
+        TomoM3 Rz = tomo_rz(p[0]), Rx = tomo_rx(p[1]), Ry = tomo_ry(p[2]);
+        TomoM3 B = tomo_mm(Ry, tomo_mm(Rx, Rz));
+        const double t[3] = {p[3], p[4], p[5]};
+        double rt[3], bo[3];
+        tomo_mv(Ry, t, rt);
+        tomo_mv(B, g.org, bo);
+        h[i].u0 = bo[0] + rt[0] - g.org[0];                      // :45 (u = x'_1 - origin_1)
+        h[i].ux = B.m[0][0] * ctx->vox_pitch[0]; h[i].uy = B.m[0][1] * ctx->vox_pitch[1]; h[i].uz = B.m[0][2] * ctx->vox_pitch[2];
+        h[i].v0 = bo[2] + rt[2] - g.org[2];                      // :46 (v = x'_3 - origin_3)
+        h[i].vx = B.m[2][0] * ctx->vox_pitch[0]; h[i].vy = B.m[2][1] * ctx->vox_pitch[1]; h[i].vz = B.m[2][2] * ctx->vox_pitch[2];
+    }
+    if (n_proj) TOMO_HIP(ctx, hipMemcpyAsync(ctx->d_stage, h, sizeof(BpC) * (size_t)n_proj, hipMemcpyHostToDevice, ctx->stream));
+    TOMO_LAUNCH(ctx, "k_bp_voxel", k_bp_voxel, dim3((g.nz + 63) / 64, (g.ny + 3) / 4, g.nx), dim3(256), 0, (const BpC *)ctx->d_stage,
+                n_proj, d_det, d_vol, g);
+    return TOMO_OK;
+}
+
+extern "C" int tomo_proj_grad(tomo_ctx *ctx, const double *h_pose, const float *d_vol, float *d_proj, float *d_grad, int row_order)
+{
+    TOMO_NEED_GEOM(ctx);
+    if (!h_pose || !d_vol || !d_proj || !d_grad || (row_order != 0 && row_order != 1))
+        return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_proj_grad: bad args");
+    const TomoGeomC &g = ctx->g;
+    int rc = stage_volume(ctx, d_vol);
+    if (rc) return rc;
+    ProjC *d_pc = nullptr;
+    GradC *d_gc = nullptr;
+    rc = upload_projc(ctx, h_pose, 1, true, &d_pc, &d_gc);
+    if (rc) return rc;
+    TOMO_LAUNCH(ctx, "k_proj_grad", k_proj_grad<false>, ray_grid(g, 1), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, d_proj, d_grad,
+                (const float *)nullptr, (float *)nullptr, (double *)nullptr, g, row_order);
+    return TOMO_OK;
+}
+
+extern "C" int tomo_cost_grad(tomo_ctx *ctx, const double *h_poses, int n, const float *d_vol, const float *d_b, double *h_cost,
+                              double *h_grad6, float *d_resid)
+{
+    TOMO_NEED_GEOM(ctx);
+    if (!h_poses || !d_vol || !d_b || !h_cost || !h_grad6 || n < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_cost_grad: bad args");
+    if (n == 0) return TOMO_OK;
+    if (n > TOMO_MAX_GRID_Z) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "tomo_cost_grad: more than 65535 projections per call");
+    const TomoGeomC &g = ctx->g;
+    int rc = stage_volume(ctx, d_vol);
+    if (rc) return rc;
+    rc = tomo_ensure_red(ctx, (size_t)n * 7 + 8);
+    if (rc) return rc;
+    ProjC *d_pc = nullptr;
+    GradC *d_gc = nullptr;
+    rc = upload_projc(ctx, h_poses, n, true, &d_pc, &d_gc);
+    if (rc) return rc;
+    TOMO_HIP(ctx, hipMemsetAsync(ctx->d_red, 0, sizeof(double) * (size_t)n * 7, ctx->stream));
+    TOMO_LAUNCH(ctx, "k_cost_grad", k_proj_grad<true>, ray_grid(g, n), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, (float *)nullptr,
+                (float *)nullptr, d_b, d_resid, ctx->d_red, g, 0);
+    TOMO_HIP(ctx, hipMemcpyAsync(ctx->h_red, ctx->d_red, sizeof(double) * (size_t)n * 7, hipMemcpyDeviceToHost, ctx->stream));
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; ++i) {
+        h_cost[i] = ctx->h_red[(size_t)i * 7];
+        for (int k = 0; k < 6; ++k) h_grad6[(size_t)i * 6 + k] = ctx->h_red[(size_t)i * 7 + 1 + k];
+    }
+    return TOMO_OK;
+}
+
+extern "C" int tomo_triplets(tomo_ctx *ctx, const double *, int64_t, int32_t *, int32_t *, double *, int64_t *)
+{
+    return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "tomo_triplets: not built yet");
+}

@@ -1,0 +1,169 @@
+// tomo_raycore.h -- per-projection constants and per-ray sample arithmetic shared by every kernel.
+//
+// Semantics restated (not translated) from the reference:
+//   pose / ray set-up   utilities/ray_voxel_utilities.py:6-12,72-94   (float64, as the reference)
+//   floor / weights     utilities/ray_voxel_utilities.py:96-99
+//   corner rule         src/ray_wt_grad.f90:35-89 (each corner contributes iff in bounds)
+//   pose Jacobian       utilities/ray_voxel_utilities.py:15-50
+//
+// Design (MI355X-first): a parallel-beam projection is an affine lattice
+//     p(ix, iz, j) = p0 + ix*u + iz*w + j*d            (index space = world - vox_origin)
+// so a projection is 13 doubles of constants instead of the reference's (3, n_rays, n) float64
+// temporaries.  Volumes are read through a zero halo of TOMO_HALO voxels, which turns the
+// per-corner bounds tests into plain loads of zeros (identical result: an out-of-bounds corner
+// contributes 0).  Sample positions inside a block of TOMO_JB samples are float32 offsets from a
+// float64 integer anchor, so coordinates keep ~2e-6 voxel accuracy at 1024^3 where plain float32
+// (ulp 6e-5 at 1024) would not.
+#ifndef TOMO_RAYCORE_H_
+#define TOMO_RAYCORE_H_
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define TOMO_HD __host__ __device__ __forceinline__
+#else
+#define TOMO_HD inline
+#endif
+
+#define TOMO_HALO 2   // zero voxels on every side of the padded volume
+#define TOMO_JB 32    // samples per re-anchored block
+
+struct TomoGeomC {    // device-side copy of tomo_geom
+    int32_t nx, ny, nz, ndx, ndz;
+    int32_t nxp, nyp, nzp;   // padded dims = n + 2*TOMO_HALO
+    double org[3], det_x0, det_z0, det_dx, det_dz, src_y, det_y, step;
+};
+
+struct ProjC {        // one projection's ray lattice (index space)
+    double p0[3], u[3], w[3], d[3];
+    double rlen;      // |r_0|                       ray_voxel_utilities.py:86
+    int32_t n;        // samples per ray = int(rlen/step)   :88
+    int32_t pad_;
+};
+
+struct GradC {        // extras for the 6-DoF pose Jacobian of one projection (:25-49)
+    double rzx[3][3];                   // Rz*Rx            (der rows 0-2 are its columns)
+    double a3[3][3], a4[3][3], a5[3][3]; // dRz*Rx, Rz*dRx, Rz*Rx*dRy
+    double ry[3][3], t[3];
+    double s00[3], sdx, sdz;            // untransformed (cor-shifted) source of ray (0,0) and pitches
+    double app[3][3];                   // der rows 6-8: the three operators applied to (d - s)
+};
+
+struct TomoM3 { double m[3][3]; };
+static inline TomoM3 tomo_rz(double a) { double c = cos(a), s = sin(a); return {{{c, -s, 0}, {s, c, 0}, {0, 0, 1}}}; }
+static inline TomoM3 tomo_rx(double a) { double c = cos(a), s = sin(a); return {{{1, 0, 0}, {0, c, -s}, {0, s, c}}}; }
+static inline TomoM3 tomo_ry(double a) { double c = cos(a), s = sin(a); return {{{c, 0, s}, {0, 1, 0}, {-s, 0, c}}}; }
+static inline TomoM3 tomo_drz(double a) { double c = cos(a), s = sin(a); return {{{-s, -c, 0}, {c, -s, 0}, {0, 0, 0}}}; }
+static inline TomoM3 tomo_drx(double a) { double c = cos(a), s = sin(a); return {{{0, 0, 0}, {0, -s, -c}, {0, c, -s}}}; }
+static inline TomoM3 tomo_dry(double a) { double c = cos(a), s = sin(a); return {{{-s, 0, c}, {0, 0, 0}, {-c, 0, -s}}}; }
+static inline TomoM3 tomo_mm(const TomoM3 &a, const TomoM3 &b)
+{
+    TomoM3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
+    return r;
+}
+static inline void tomo_mv(const TomoM3 &a, const double x[3], double o[3])
+{
+    for (int i = 0; i < 3; ++i) o[i] = a.m[i][0] * x[0] + a.m[i][1] * x[1] + a.m[i][2] * x[2];
+}
+
+// pose = phi, alpha, beta, tx, ty, tz, cor_x
+static inline void tomo_make_projc(const TomoGeomC &g, const double *pose, ProjC &c, GradC *gc)
+{
+    const double phi = pose[0], alpha = pose[1], beta = pose[2];
+    const double t[3] = {pose[3], pose[4], pose[5]};
+    const double cor = pose[6];
+    TomoM3 Rz = tomo_rz(phi), Rx = tomo_rx(alpha), Ry = tomo_ry(beta);
+    TomoM3 Rzx = tomo_mm(Rz, Rx);                                   // :8
+    TomoM3 M = tomo_mm(Rzx, Ry);
+    const double s00[3] = {g.det_x0 + cor, g.src_y, g.det_z0};      // :72  (geometry.py:99)
+    const double d00[3] = {g.det_x0 + cor, g.det_y, g.det_z0};      // :73  (geometry.py:100)
+    double q[3], ps[3], pd[3];
+    tomo_mv(Ry, s00, q);
+    for (int a = 0; a < 3; ++a) q[a] += t[a];                       // :9
+    tomo_mv(Rzx, q, ps);                                            // :10
+    tomo_mv(Ry, d00, q);
+    for (int a = 0; a < 3; ++a) q[a] += t[a];
+    tomo_mv(Rzx, q, pd);
+    double r[3], r2 = 0;
+    for (int a = 0; a < 3; ++a) {
+        c.p0[a] = ps[a] - g.org[a];                                 // :74
+        r[a] = (pd[a] - g.org[a]) - c.p0[a];                        // :85
+        r2 += r[a] * r[a];
+        c.u[a] = M.m[a][0] * g.det_dx;
+        c.w[a] = M.m[a][2] * g.det_dz;
+    }
+    c.rlen = sqrt(r2);                                              // :86
+    for (int a = 0; a < 3; ++a) c.d[a] = g.step * (r[a] / c.rlen);  // :87,93
+    c.n = (int32_t)(c.rlen / g.step);                               // :88
+    c.pad_ = 0;
+    if (gc) {
+        TomoM3 dRz = tomo_drz(phi), dRx = tomo_drx(alpha), dRy = tomo_dry(beta);
+        TomoM3 A3 = tomo_mm(dRz, Rx), A4 = tomo_mm(Rz, dRx), A5 = tomo_mm(Rzx, dRy);
+        TomoM3 Rab = tomo_mm(Rx, Ry);
+        const double rv[3] = {0.0, g.det_y - g.src_y, 0.0};         // untransformed ray  :158
+        double tmp[3], tmp2[3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                gc->rzx[i][j] = Rzx.m[i][j];
+                gc->a3[i][j] = A3.m[i][j];
+                gc->a4[i][j] = A4.m[i][j];
+                gc->a5[i][j] = A5.m[i][j];
+                gc->ry[i][j] = Ry.m[i][j];
+            }
+        for (int a = 0; a < 3; ++a) { gc->t[a] = t[a]; gc->s00[a] = s00[a]; }
+        gc->sdx = g.det_dx;
+        gc->sdz = g.det_dz;
+        tomo_mv(Rab, rv, tmp);  tomo_mv(dRz, tmp, gc->app[0]);      // :47
+        tomo_mv(Ry, rv, tmp);   tomo_mv(dRx, tmp, tmp2); tomo_mv(Rz, tmp2, gc->app[1]);  // :48
+        tomo_mv(dRy, rv, tmp);  tomo_mv(Rzx, tmp, gc->app[2]);      // :49
+    }
+}
+
+// {t : lo <= b + t*d < hi} intersected into [t0, t1]
+TOMO_HD void tomo_clip_axis(double b, double d, double lo, double hi, double &t0, double &t1)
+{
+    if (d != 0.0) {
+        double ta = (lo - b) / d, tb = (hi - b) / d;
+        if (ta > tb) { double s = ta; ta = tb; tb = s; }
+        t0 = t0 > ta ? t0 : ta;
+        t1 = t1 < tb ? t1 : tb;
+    } else if (b < lo || b >= hi) {
+        t0 = 1.0;
+        t1 = 0.0;
+    }
+}
+
+// Sample range [j0, j1) of a ray outside which every corner of every sample is out of bounds
+// (floor(p_a) in [-1, n_a-1] <=> p_a in [-1, n_a)).  Rounded outward by 1e-6 samples only, so all
+// computed floors stay inside the TOMO_HALO=2 padding (float32 in-block error ~1e-5 voxel).
+TOMO_HD void tomo_ray_range(const double b[3], const double d[3], int n, int nx, int ny, int nz, int &j0, int &j1)
+{
+    double t0 = 0.0, t1 = (double)(n - 1);
+    tomo_clip_axis(b[0], d[0], -1.0, (double)nx, t0, t1);
+    tomo_clip_axis(b[1], d[1], -1.0, (double)ny, t0, t1);
+    tomo_clip_axis(b[2], d[2], -1.0, (double)nz, t0, t1);
+    if (!(t0 <= t1)) { j0 = 0; j1 = 0; return; }
+    j0 = (int)ceil(t0 - 1e-6);
+    j1 = (int)floor(t1 + 1e-6) + 1;
+    if (j0 < 0) j0 = 0;
+    if (j1 > n) j1 = n;
+    if (j1 < j0) j1 = j0;
+}
+
+// Block anchor: one below the integer floor of the smallest coordinate the block [jb, jb+TOMO_JB)
+// reaches, so in-block offsets are >= 1 (their floors stay >= 0 under float32 rounding, which the
+// unsigned 24-bit offset arithmetic of the kernels relies on) and < TOMO_JB*|d|+3.
+TOMO_HD void tomo_block_anchor(const double b[3], const double d[3], int jb, int ia[3], float f0[3])
+{
+    for (int a = 0; a < 3; ++a) {
+        double s = b[a] + (double)jb * d[a];
+        double e = s + (double)(TOMO_JB - 1) * d[a];
+        double f = floor(s < e ? s : e) - 1.0;
+        ia[a] = (int)f;
+        f0[a] = (float)(s - f);
+    }
+}
+
+#endif  // TOMO_RAYCORE_H_

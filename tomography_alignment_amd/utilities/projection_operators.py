@@ -1,0 +1,211 @@
+"""
+Drop-in for the reference's utilities/projection_operators.py:11-122 `ProjectionMatrix`.
+
+`projection_matrix(...)` keeps the reference signature but returns a MATRIX-FREE operator living on
+the MI355X instead of a scipy CSR (the reference's CSR is 4.5 GB at 128^3 x 64 angles and cannot
+exist at 256^3).  The returned object answers the *unbound* scipy calls the reference's solvers make:
+
+    sparse.csr_matrix.dot(A, x)                                   recon/sirt.py:59
+    sparse.csc_matrix.dot(sparse.csr_matrix.transpose(A), y)      recon/sirt.py:61
+
+(scipy's `_spbase.dot` does `self @ other`; `_csr_base.transpose` reads `ndim`, `shape`, `data`,
+`indices`, `indptr` and calls `self._csc_container(...)`), so recon/sirt.py runs unmodified.
+`projection_gradient(...)` returns `(proj[n_det], grad[6, n_det])` exactly like
+utilities/projection_operators.py:112-122, rows tx, ty, tz, phi, alpha, beta.
+"""
+import numpy as np
+
+from .. import _lib
+from ..backend import HipBackend
+
+
+def _normalise_poses(geometry, alpha, beta, phi, xyz_shift):
+    """Defaults and n_proj==1 re-wrapping of utilities/projection_operators.py:24-52."""
+    if phi is None:
+        n_proj = int(geometry.n_proj)
+        phi = np.linspace(0., np.pi, n_proj)
+    else:
+        n_proj = int(np.size(phi))
+    alpha = np.zeros(n_proj) if alpha is None else alpha
+    beta = np.zeros(n_proj) if beta is None else beta
+    xyz_shift = np.zeros((n_proj, 3)) if xyz_shift is None else xyz_shift
+    phi = np.asarray(phi, np.float64).reshape(n_proj)
+    alpha = np.asarray(alpha, np.float64).reshape(n_proj)
+    beta = np.asarray(beta, np.float64).reshape(n_proj)
+    xyz_shift = np.asarray(xyz_shift, np.float64).reshape(n_proj, 3)
+    return n_proj, phi, alpha, beta, xyz_shift
+
+
+class RayOperator(object):
+    """A (n_proj*n_det) x n_vox linear operator: forward projection A and, as `.T`, its exact adjoint."""
+
+    ndim = 2
+    format = "rayop"
+    # scipy's csr transpose passes these through to _csc_container; they are never dereferenced
+    data = None
+    indices = None
+    indptr = None
+
+    def __init__(self, backend, poses, precision=np.float32, voxel_mask=None, _adjoint_of=None):
+        self.backend = backend
+        self.poses = poses
+        self.precision = precision
+        self.dtype = np.dtype(precision)
+        self._is_adjoint = _adjoint_of is not None
+        self._fwd = _adjoint_of if self._is_adjoint else self
+        n_rows = poses.shape[0] * backend.n_det
+        self.shape = (backend.n_vox, n_rows) if self._is_adjoint else (n_rows, backend.n_vox)
+        if not self._is_adjoint:
+            self._mask = None
+            if voxel_mask is not None:
+                m = np.asarray(voxel_mask).ravel().astype(bool)
+                if m.size != backend.n_vox:
+                    raise ValueError("voxel_mask must have n_vox elements")
+                if not m.any():
+                    print('entire object is masked')      # utilities/projection_operators.py:64-66
+                self._mask = backend.upload(m.astype(np.float32))
+            self._T = None
+            self._scratch = {}
+
+    # -- scipy unbound-method protocol -----------------------------------------------------------
+    def _csc_container(self, *args, **kwargs):
+        return self.transpose()
+
+    _csr_container = _csc_container
+
+    def transpose(self, axes=None, copy=False):
+        if self._is_adjoint:
+            return self._fwd
+        if self._T is None:
+            self._T = RayOperator(self.backend, self.poses, self.precision, _adjoint_of=self)
+        return self._T
+
+    @property
+    def T(self):
+        return self.transpose()
+
+    def __matmul__(self, other):
+        return self.dot(other)
+
+    def __mul__(self, other):
+        return self.dot(other)
+
+    def matvec(self, x):
+        return self.dot(x)
+
+    def rmatvec(self, y):
+        return self.transpose().dot(y)
+
+    # -- application -----------------------------------------------------------------------------
+    def _buf(self, key, n):
+        f = self._fwd
+        b = f._scratch.get(key)
+        if b is None or b.size != n:
+            b = f.backend.empty(n)
+            f._scratch[key] = b
+        return b
+
+    def apply(self, x_dev, out_dev=None):
+        """Device-resident application: DeviceArray in, DeviceArray out (no PCIe traffic)."""
+        be, f = self.backend, self._fwd
+        if not self._is_adjoint:
+            if out_dev is None:
+                out_dev = be.empty(self.shape[0])
+            src = x_dev
+            if f._mask is not None:
+                src = self._buf("masked", be.n_vox)
+                be.copy(src, x_dev)
+                be.mul(src, f._mask)
+            return be.forward(self.poses, src, out_dev)
+        if out_dev is None:
+            out_dev = be.empty(self.shape[0])
+        be.adjoint(self.poses, x_dev, out_dev)
+        if f._mask is not None:
+            be.mul(out_dev, f._mask)
+        return out_dev
+
+    def dot(self, other):
+        be = self.backend
+        if be.is_buffer(other):
+            return self.apply(other)
+        x = np.asarray(other)
+        if x.ndim == 2 and x.shape[1] == 1:
+            return self.dot(x[:, 0])[:, np.newaxis]
+        if x.size != self.shape[1]:
+            raise ValueError("dimension mismatch: operator %s, operand %s" % (self.shape, x.shape))
+        xin = self._buf("in%d" % self._is_adjoint, self.shape[1])
+        xin.upload(x.ravel())
+        out = self.apply(xin, self._buf("out%d" % self._is_adjoint, self.shape[0]))
+        res = out.download()
+        return res if self.dtype == np.float32 else res.astype(self.dtype)
+
+    def tocsr(self):
+        raise NotImplementedError("matrix-free operator: CSR materialisation is only offered for small volumes "
+                                  "via ProjectionMatrix.assemble_csr()")
+
+
+class ProjectionMatrix(object):
+
+    def __init__(self, geometry, precision=np.float32, backend=None):
+        self.geometry = geometry
+        self.precision = precision
+        self.n_proj = None
+        self.angles = None
+        self.xyz_shift = None
+        self.voxel_mask = None
+        self._backend = backend
+        self._vol_key = None
+        self._vol_dev = None
+        self._pg_bufs = None
+
+    @property
+    def backend(self):
+        if self._backend is None:
+            self._backend = HipBackend(self.geometry)     # raises if libtomo_hip.so / GPU is missing
+        return self._backend
+
+    def projection_matrix(self, alpha=None, beta=None, phi=None, xyz_shift=None, voxel_mask=None):
+        n_proj, phi, alpha, beta, xyz_shift = _normalise_poses(self.geometry, alpha, beta, phi, xyz_shift)
+        self.n_proj = n_proj
+        self.angles = np.array([phi, alpha, beta]).T
+        self.xyz_shift = xyz_shift
+        self.voxel_mask = voxel_mask
+        cor = np.asarray(self.geometry.cor_shift, np.float64)
+        if cor.ndim == 2 and cor.shape[0] != n_proj:
+            raise ValueError("geometry.cor_shift has %d rows for %d projections" % (cor.shape[0], n_proj))
+        poses = _lib.poses_array(phi, alpha, beta, xyz_shift, cor)
+        return RayOperator(self.backend, poses, self.precision, voxel_mask)
+
+    # ---- volume residency for repeated projection_gradient calls (alignment inner loop)
+    def set_volume(self, rec):
+        """Pin `rec` (host array or DeviceArray) in HBM for subsequent projection_gradient calls."""
+        be = self.backend
+        if be.is_buffer(rec):
+            self._vol_dev, self._vol_key = rec, ("dev", id(rec))
+            return rec
+        a = np.asarray(rec)
+        flat = a.reshape(-1)
+        stride = max(1, flat.size // 4096)
+        key = (a.__array_interface__['data'][0], a.shape, str(a.dtype), float(np.sum(flat[::stride], dtype=np.float64)),
+               float(flat[-1]))
+        if key != self._vol_key:
+            if self._vol_dev is None or self._vol_key is None or self._vol_key[0] == "dev" or self._vol_dev.size != flat.size:
+                self._vol_dev = be.empty(flat.size)
+            self._vol_dev.upload(flat)
+            self._vol_key = key
+        return self._vol_dev
+
+    def pose_row(self, alpha, beta, phi, xyz_shift, cor_shift):
+        return _lib.poses_array([phi], [alpha], [beta], np.asarray(xyz_shift, np.float64).reshape(1, 3),
+                                np.asarray(cor_shift, np.float64).reshape(-1)[:3])
+
+    def projection_gradient(self, rec, alpha, beta, phi, xyz_shift, cor_shift):
+        be = self.backend
+        vol = self.set_volume(rec)
+        if self._pg_bufs is None:
+            self._pg_bufs = (be.empty(be.n_det), be.empty(6 * be.n_det))
+        p_dev, g_dev = self._pg_bufs
+        be.proj_grad(self.pose_row(alpha, beta, phi, xyz_shift, cor_shift), vol, p_dev, g_dev, 0)
+        proj_img = p_dev.download().astype(self.precision, copy=False)
+        gradient = g_dev.download().astype(self.precision, copy=False)
+        return proj_img.ravel(), gradient.reshape(6, -1)

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Ad-hoc kernel timing on the GPU box (development aid; the judged numbers come from bench.py)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tomography_alignment_amd import _lib  # noqa: E402
+from tomography_alignment_amd.backend import HipBackend  # noqa: E402
+from tomography_alignment_amd.utilities.geometry import Geometry  # noqa: E402
+
+
+def poses(n_proj, tilt, rng):
+    phi = np.linspace(0, np.pi, n_proj)
+    if tilt:
+        a = np.deg2rad(rng.uniform(-1, 1, n_proj)); b = np.deg2rad(rng.uniform(-1, 1, n_proj))
+        xyz = np.zeros((n_proj, 3)); xyz[:, 0] = rng.uniform(-2, 2, n_proj); xyz[:, 2] = rng.uniform(-2, 2, n_proj)
+    else:
+        a = np.zeros(n_proj); b = np.zeros(n_proj); xyz = np.zeros((n_proj, 3))
+    return _lib.poses_array(phi, a, b, xyz, np.zeros(3))
+
+
+def run(N, n_proj, what, tilt=True, reps=2, opts=None):
+    rng = np.random.default_rng(0)
+    geo = Geometry(n_proj, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
+    be = HipBackend(geo)
+    for k, v in (opts or {}).items():
+        be.ctx.set_option(k, v)
+    vol = be.zeros(N ** 3); be.fill(vol, 1.0)
+    prj = be.zeros(n_proj * N * N); be.fill(prj, 1.0)
+    P = poses(n_proj, tilt, rng)
+    fn = {"fwd": lambda: be.forward(P, vol, prj), "adj": lambda: be.adjoint(P, prj, vol),
+          "bpv": lambda: be.backproject_voxel(P, prj, vol)}[what]
+    fn(); be.sync()
+    best = 1e30
+    for _ in range(reps):
+        be.ctx.timer_start(); fn(); ms = be.ctx.timer_stop(); best = min(best, ms)
+    alg = {"fwd": 4 * N ** 3 + 4 * N * N, "adj": 8 * N ** 3 + 4 * N * N, "bpv": 8 * N ** 3 + 4 * N * N}[what] * n_proj
+    print("%-4s N=%4d n_proj=%4d tilt=%d opts=%s : %9.2f ms  alg %.1f GB/s  (%.1f%% of 8 TB/s)  [%.3f ms/angle]"
+          % (what, N, n_proj, tilt, opts, best, alg / best / 1e6, alg / best / 1e6 / 80.0, best / n_proj), flush=True)
+    del vol, prj
+    be.ctx.close()
+
+
+if __name__ == "__main__":
+    jobs = sys.argv[1:] or ["fwd:256:256", "fwd:512:64", "fwd:1024:16", "adj:256:32", "bpv:256:64"]
+    for j in jobs:
+        parts = j.split(":")
+        what, N, n_proj = parts[0], int(parts[1]), int(parts[2])
+        opts = {}
+        for kv in parts[3:]:
+            k, v = kv.split("=")
+            if k == "tilt":
+                continue
+            opts[k] = int(v)
+        tilt = not any(p == "tilt=0" for p in parts[3:])
+        run(N, n_proj, what, tilt=tilt, opts=opts)
