@@ -253,16 +253,21 @@ __global__ __launch_bounds__(256) void k_adj_v1(const ProjC *__restrict__ pcs, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// adjoint, variant 2: volume-tile-owned scatter into LDS.
+// adjoint, variant 2: volume-tile-owned scatter into LDS, fixed-point.
 //
-// A work-group owns the samples whose floor cell lies in a ATX x ATY x ATZ voxel tile (tile grid
-// starts at -1 so the floor=-1 shell is owned too) and accumulates their 8 corner contributions with
-// LDS float atomics (ds_add_f32) into a (ATX+1)(ATY+1)(ATZ+1) LDS image, for ALL projections of the
-// call; the image is flushed once with global float atomics (~1.2x the volume bytes per call instead
-// of 8 atomics per sample -- MI355X global float atomics run at ~1.3 TB/s, LDS at tens of TB/s).
-// Lanes run along detector-z (consecutive LDS banks), the 8 waves of the work-group take different
-// detector-x rows; a row's sample range comes from clipping its centre line against the tile box
-// widened by the lanes' lateral spread, every lane masks itself by exact ownership.
+// A work-group owns the samples whose floor cell lies in an ATX x ATY x ATZ voxel tile (the tile grid
+// starts at -1 so the floor = -1 shell is owned too) and accumulates their 8 corner contributions into
+// a (ATX+1)(ATY+1)(ATZ+1) LDS image.  Measured on MI355X (tools/lds_atomic_bench.hip): ds_add_f32 costs
+// ~170 cycles per wave-op, ds_add_u32 ~4 -- so contributions are converted to 32-bit fixed point
+// (scale from the sinogram's abs-max, found on the device) and added with ds_add_u32; integer adds
+// commute, so the LDS image does not depend on wave scheduling.  Every ADJ_BATCH projections the
+// image is converted back and flushed with global float atomics (~1.2x the volume bytes per batch
+// instead of 8 global atomics per sample at the chip-wide ~1.3 TB/s atomic rate).
+// Lanes run along detector-z (consecutive LDS banks); the 8 waves take different detector-x rows.  A
+// row's sample range comes from clipping its centre line against the tile box widened by the lanes'
+// lateral spread; each lane then masks itself by exact ownership.  Cell indices and weights come
+// from the same tile-independent block anchors as the forward kernel (tomo_block_anchor), so
+// neighbouring tiles agree bit-for-bit on who owns a sample and A^T uses exactly A's weights.
 // ------------------------------------------------------------------------------------------------
 #define ATX 16
 #define ATY 16
@@ -271,6 +276,7 @@ __global__ __launch_bounds__(256) void k_adj_v1(const ProjC *__restrict__ pcs, c
 #define ALY (ATY + 1)
 #define ALZ (ATZ + 1)
 #define ADJ_WAVES 8
+#define ADJ_BATCH 64
 
 struct AdjC {
     double p0[3], u[3], w[3], d[3];
@@ -278,104 +284,137 @@ struct AdjC {
     int32_t n, pad_;
 };
 
-__global__ __launch_bounds__(ADJ_WAVES * 64) void k_adj_tile(const AdjC *__restrict__ pcs, int n_proj, const float *__restrict__ proj,
-                                                             float *__restrict__ vol, TomoGeomC g)
+__global__ __launch_bounds__(256) void k_absmax(const float *__restrict__ v, int64_t n, unsigned *__restrict__ out)
 {
-    __shared__ float acc[ALX * ALY * ALZ];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(v[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));   // non-negative floats order like their bit patterns
+}
+
+__device__ __forceinline__ int cvt_round_i32(float x)
+{
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));   // floor(x + 0.5) in one instruction
+    return r;
+}
+
+__global__ __launch_bounds__(ADJ_WAVES * 64) void k_adj_tile(const AdjC *__restrict__ pcs, int n_proj, const float *__restrict__ proj,
+                                                             float *__restrict__ vol, TomoGeomC g, const unsigned *__restrict__ absmax_bits,
+                                                             float weight_bound)
+{
+    __shared__ int acc[ALX * ALY * ALZ];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int z0 = -1 + (int)blockIdx.x * ATZ, y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + (int)blockIdx.z * ATX;
-    for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) acc[e] = 0.f;
+    const float ymax = __uint_as_float(*absmax_bits);
+    if (!(ymax > 0.f)) return;                                   // A^T 0 = 0 (vol already holds the right answer)
+    // |image| <= ADJ_BATCH * ymax * weight_bound  ->  keep it below 2^30
+    const float scale = 1073741824.f / ((float)min(n_proj, ADJ_BATCH) * ymax * weight_bound);
+    const float inv_scale = 1.f / scale;
+    for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) acc[e] = 0;
     __syncthreads();
     const double blo[3] = {(double)x0, (double)y0, (double)z0};
     const double bhi[3] = {(double)(x0 + ATX), (double)(y0 + ATY), (double)(z0 + ATZ)};
     const size_t n_det = (size_t)g.ndx * g.ndz;
 
-    for (int ip = 0; ip < n_proj; ++ip) {
-        const AdjC &c = pcs[ip];
-        // lattice-coordinate ranges of the owned box (linear functionals: extremes at the 8 corners)
-        double ixl = 1e300, ixh = -1e300, izl = 1e300, izh = -1e300;
+    for (int ip0 = 0; ip0 < n_proj; ip0 += ADJ_BATCH) {
+        const int ip1 = min(n_proj, ip0 + ADJ_BATCH);
+        for (int ip = ip0; ip < ip1; ++ip) {
+            const AdjC &c = pcs[ip];
+            // lattice-coordinate ranges of the owned box (linear functionals: extremes at the 8 corners)
+            double ixl = 1e300, ixh = -1e300, izl = 1e300, izh = -1e300;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const double qx = ((k & 1) ? bhi[0] : blo[0]) - c.p0[0];
-            const double qy = ((k & 2) ? bhi[1] : blo[1]) - c.p0[1];
-            const double qz = ((k & 4) ? bhi[2] : blo[2]) - c.p0[2];
-            const double fi = c.minv[0][0] * qx + c.minv[0][1] * qy + c.minv[0][2] * qz;
-            const double fz = c.minv[1][0] * qx + c.minv[1][1] * qy + c.minv[1][2] * qz;
-            ixl = fmin(ixl, fi); ixh = fmax(ixh, fi);
-            izl = fmin(izl, fz); izh = fmax(izh, fz);
-        }
-        const int ix_lo = max(0, (int)ceil(fmax(ixl, -1.0) - 1e-6));
-        const int ix_hi = min(g.ndx - 1, (int)floor(fmin(ixh, (double)g.ndx) + 1e-6));
-        if (ix_lo > ix_hi) continue;
-        izl = fmax(izl, 0.0);
-        izh = fmin(izh, (double)(g.ndz - 1));
-        if (izl > izh + 1.0) continue;
-        const double izc = 0.5 * (izl + izh), hs = 0.5 * (izh - izl) + 1.0;   // lanes' iz spread about the centre line
-        const float dxf = (float)c.d[0], dyf = (float)c.d[1], dzf = (float)c.d[2];
-
-        for (int ix = ix_lo + wv; ix <= ix_hi; ix += ADJ_WAVES) {
-            // sample range of this detector row: centre line clipped against the box widened by the lanes' spread
-            double cb[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) cb[a] = c.p0[a] + (double)ix * c.u[a] + izc * c.w[a];
-            double t0 = 0.0, t1 = (double)(c.n - 1);
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double h = fabs(c.w[a]) * hs + 1e-6;
-                tomo_clip_axis(cb[a], c.d[a], blo[a] - h, bhi[a] + h, t0, t1);
+            for (int k = 0; k < 8; ++k) {
+                const double qx = ((k & 1) ? bhi[0] : blo[0]) - c.p0[0];
+                const double qy = ((k & 2) ? bhi[1] : blo[1]) - c.p0[1];
+                const double qz = ((k & 4) ? bhi[2] : blo[2]) - c.p0[2];
+                const double fi = c.minv[0][0] * qx + c.minv[0][1] * qy + c.minv[0][2] * qz;
+                const double fz = c.minv[1][0] * qx + c.minv[1][1] * qy + c.minv[1][2] * qz;
+                ixl = fmin(ixl, fi); ixh = fmax(ixh, fi);
+                izl = fmin(izl, fz); izh = fmax(izh, fz);
             }
-            if (!(t0 <= t1)) continue;
-            const int jlo = max(0, (int)ceil(t0 - 1e-6)), jhi = min(c.n, (int)floor(t1 + 1e-6) + 1);
-            if (jhi <= jlo) continue;
-            // detector-z lanes needed for ownership in z over j in [jlo, jhi)
-            const double cz = c.p0[2] + (double)ix * c.u[2];
-            const double zj0 = (double)jlo * c.d[2], zj1 = (double)(jhi - 1) * c.d[2];
-            const double zjmin = fmin(zj0, zj1), zjmax = fmax(zj0, zj1);
-            const int iz_first = max(0, (int)floor((blo[2] - cz - zjmax) / c.w[2] - 1e-6));
-            const int iz_last = min(g.ndz - 1, (int)ceil((bhi[2] - cz - zjmin) / c.w[2] + 1e-6));
-            for (int izb = iz_first; izb <= iz_last; izb += 64) {
-                const int iz = izb + lane;
-                const bool lane_ok = iz <= iz_last;
-                const int izc_ = lane_ok ? iz : iz_last;
-                const float yv = lane_ok ? proj[(size_t)ip * n_det + (size_t)ix * g.ndz + izc_] : 0.f;
-                // tile-local float32 position of sample jlo (float64 set-up: |local| < ~100 => ulp 8e-6)
-                const float bx = (float)(c.p0[0] + (double)ix * c.u[0] + (double)izc_ * c.w[0] + (double)jlo * c.d[0] - blo[0]);
-                const float by = (float)(c.p0[1] + (double)ix * c.u[1] + (double)izc_ * c.w[1] + (double)jlo * c.d[1] - blo[1]);
-                const float bz = (float)(c.p0[2] + (double)ix * c.u[2] + (double)izc_ * c.w[2] + (double)jlo * c.d[2] - blo[2]);
-                const int cnt = jhi - jlo;
-                for (int jj = 0; jj < cnt; ++jj) {
-                    const float t = (float)jj;
-                    const float x = fmaf(t, dxf, bx), y = fmaf(t, dyf, by), z = fmaf(t, dzf, bz);
-                    const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-                    const int lx = (int)fx, ly = (int)fy, lz = (int)fz;
-                    if (lane_ok && (unsigned)lx < (unsigned)ATX && (unsigned)ly < (unsigned)ATY && (unsigned)lz < (unsigned)ATZ) {
-                        const float wcx = x - fx, wcy = y - fy, wcz = z - fz;
-                        const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
-                        const float a0 = yv * wfx, a1 = yv * wcx;
-                        const float b00 = a0 * wfy, b01 = a0 * wcy, b10 = a1 * wfy, b11 = a1 * wcy;
-                        float *q = &acc[(lx * ALY + ly) * ALZ + lz];
-                        atomicAdd(q, b00 * wfz);
-                        atomicAdd(q + 1, b00 * wcz);
-                        atomicAdd(q + ALZ, b01 * wfz);
-                        atomicAdd(q + ALZ + 1, b01 * wcz);
-                        atomicAdd(q + ALY * ALZ, b10 * wfz);
-                        atomicAdd(q + ALY * ALZ + 1, b10 * wcz);
-                        atomicAdd(q + ALY * ALZ + ALZ, b11 * wfz);
-                        atomicAdd(q + ALY * ALZ + ALZ + 1, b11 * wcz);
+            const int ix_lo = max(0, (int)ceil(fmax(ixl, -1.0) - 1e-6));
+            const int ix_hi = min(g.ndx - 1, (int)floor(fmin(ixh, (double)g.ndx) + 1e-6));
+            if (ix_lo > ix_hi) continue;
+            izl = fmax(izl, 0.0);
+            izh = fmin(izh, (double)(g.ndz - 1));
+            if (izl > izh + 1.0) continue;
+            const double izc = 0.5 * (izl + izh), hs = 0.5 * (izh - izl) + 1.0;   // lanes' iz spread about the centre line
+            const float dxf = (float)c.d[0], dyf = (float)c.d[1], dzf = (float)c.d[2];
+
+            for (int ix = ix_lo + wv; ix <= ix_hi; ix += ADJ_WAVES) {
+                // sample range of this detector row: centre line clipped against the box widened by the lanes' spread
+                double t0 = 0.0, t1 = (double)(c.n - 1);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double cb = c.p0[a] + (double)ix * c.u[a] + izc * c.w[a];
+                    const double h = fabs(c.w[a]) * hs + 1e-5;
+                    tomo_clip_axis(cb, c.d[a], blo[a] - h, bhi[a] + h, t0, t1);
+                }
+                if (!(t0 <= t1)) continue;
+                const int jlo = max(0, (int)ceil(t0 - 1e-6)), jhi = min(c.n, (int)floor(t1 + 1e-6) + 1);
+                if (jhi <= jlo) continue;
+                // detector-z lanes needed for ownership in z over j in [jlo, jhi)
+                const double cz = c.p0[2] + (double)ix * c.u[2];
+                const double zj0 = (double)jlo * c.d[2], zj1 = (double)(jhi - 1) * c.d[2];
+                const double zjmin = fmin(zj0, zj1), zjmax = fmax(zj0, zj1);
+                const int iz_first = max(0, (int)floor((blo[2] - cz - zjmax) / c.w[2] - 1e-5));
+                const int iz_last = min(g.ndz - 1, (int)ceil((bhi[2] - cz - zjmin) / c.w[2] + 1e-5));
+                for (int izb = iz_first; izb <= iz_last; izb += 64) {
+                    const int iz = izb + lane;
+                    const bool lane_ok = iz <= iz_last;
+                    const int izk = lane_ok ? iz : iz_last;
+                    const float ys = (lane_ok ? proj[(size_t)ip * n_det + (size_t)ix * g.ndz + izk] : 0.f) * scale;
+                    double b[3];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) b[a] = c.p0[a] + (double)ix * c.u[a] + (double)izk * c.w[a];
+                    for (int jb = jlo & ~(TOMO_JB - 1); jb < jhi; jb += TOMO_JB) {
+                        int ia[3];
+                        float f0[3];
+                        tomo_block_anchor(b, c.d, jb, ia, f0);          // tile-independent: same bits in every tile
+                        const int ox = ia[0] - x0, oy = ia[1] - y0, oz = ia[2] - z0;
+                        const int lo = max(jlo, jb) - jb, hi = min(jhi, jb + TOMO_JB) - jb;
+                        for (int jj = lo; jj < hi; ++jj) {
+                            const float t = (float)jj;
+                            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
+                            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+                            const int lx = ox + (int)fx, ly = oy + (int)fy, lz = oz + (int)fz;
+                            if (lane_ok && (unsigned)lx < (unsigned)ATX && (unsigned)ly < (unsigned)ATY && (unsigned)lz < (unsigned)ATZ) {
+                                const float wcx = x - fx, wcy = y - fy, wcz = z - fz;
+                                const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
+                                const float a0 = ys * wfx, a1 = ys * wcx;
+                                const float b00 = a0 * wfy, b01 = a0 * wcy, b10 = a1 * wfy, b11 = a1 * wcy;
+                                int *q = &acc[(int)(__umul24((unsigned)lx, ALY) + (unsigned)ly) * ALZ + lz];
+                                atomicAdd(q, cvt_round_i32(b00 * wfz));
+                                atomicAdd(q + 1, cvt_round_i32(b00 * wcz));
+                                atomicAdd(q + ALZ, cvt_round_i32(b01 * wfz));
+                                atomicAdd(q + ALZ + 1, cvt_round_i32(b01 * wcz));
+                                atomicAdd(q + ALY * ALZ, cvt_round_i32(b10 * wfz));
+                                atomicAdd(q + ALY * ALZ + 1, cvt_round_i32(b10 * wcz));
+                                atomicAdd(q + ALY * ALZ + ALZ, cvt_round_i32(b11 * wfz));
+                                atomicAdd(q + ALY * ALZ + ALZ + 1, cvt_round_i32(b11 * wcz));
+                            }
+                        }
                     }
                 }
             }
         }
-    }
-    __syncthreads();
-    // flush: interior of the image is exclusively ours, the +1 faces are shared with neighbours => atomics
-    for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) {
-        const int lz = e % ALZ, t2 = e / ALZ, ly = t2 % ALY, lx = t2 / ALY;
-        const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
-        const float v = acc[e];
-        if (v != 0.f && gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz)
-            atomicAdd(&vol[((size_t)gx * g.ny + gy) * g.nz + gz], v);
+        __syncthreads();
+        // flush this batch: interior of the image is exclusively ours, the +1 faces are shared => global atomics
+        for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) {
+            const int v = acc[e];
+            if (v != 0) {
+                acc[e] = 0;
+                const int lz = e % ALZ, t2 = e / ALZ, ly = t2 % ALY, lx = t2 / ALY;
+                const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
+                if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz)
+                    atomicAdd(&vol[((size_t)gx * g.ny + gy) * g.nz + gz], (float)v * inv_scale);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -627,6 +666,7 @@ extern "C" int tomo_adjoint(tomo_ctx *ctx, const double *h_poses, int n_proj, co
     std::vector<int> rest_idx;
     std::vector<int> tile_idx;
     int nt = 0;
+    double weight_bound = 2.0;
     for (int i = 0; i < n_proj; ++i) {
         ProjC pc;
         tomo_make_projc(g, h_poses + (size_t)i * TOMO_POSE_STRIDE, pc, nullptr);
@@ -639,6 +679,13 @@ extern "C" int tomo_adjoint(tomo_ctx *ctx, const double *h_poses, int n_proj, co
         a.n = pc.n;
         a.pad_ = 0;
         const bool ok = invert3(m, a.minv) && pc.w[2] > 0.7 * sqrt(pc.w[0] * pc.w[0] + pc.w[1] * pc.w[1] + pc.w[2] * pc.w[2]);
+        if (ok) {
+            // samples per unit volume = 1/|det[u w d]|; the tent weights a voxel collects from one projection sum to about
+            // that density (exactly 1 for an axis-aligned unit lattice); x2 head-room
+            const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                               m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+            weight_bound = std::max(weight_bound, 2.0 / fabs(det));
+        }
         if (ok) { h[nt++] = a; tile_idx.push_back(i); }
         else { rest_idx.push_back(i); }
     }
@@ -651,8 +698,14 @@ extern "C" int tomo_adjoint(tomo_ctx *ctx, const double *h_poses, int n_proj, co
     TOMO_HIP(ctx, hipMemcpyAsync(ctx->d_stage, h, sizeof(AdjC) * (size_t)nt, hipMemcpyHostToDevice, ctx->stream));
     const dim3 grid((g.nz + 1 + ATZ - 1) / ATZ, (g.ny + 1 + ATY - 1) / ATY, (g.nx + 1 + ATX - 1) / ATX);
     if (grid.y > 65535 || grid.z > 65535) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "tomo_adjoint: volume too large for the tile grid");
-    (void)n_det;
-    TOMO_LAUNCH(ctx, "k_adj_tile", k_adj_tile, grid, dim3(ADJ_WAVES * 64), 0, (const AdjC *)ctx->d_stage, nt, d_proj, d_vol, g);
+    rc = tomo_ensure_red(ctx, 8);
+    if (rc) return rc;
+    unsigned *d_absmax = (unsigned *)(ctx->d_red + 4);
+    TOMO_HIP(ctx, hipMemsetAsync(d_absmax, 0, sizeof(unsigned), ctx->stream));
+    const int64_t n_y = (int64_t)n_det * n_proj;
+    TOMO_LAUNCH(ctx, "k_absmax", k_absmax, dim3((unsigned)std::min<int64_t>((n_y + 255) / 256, 2048)), dim3(256), 0, d_proj, n_y, d_absmax);
+    TOMO_LAUNCH(ctx, "k_adj_tile", k_adj_tile, grid, dim3(ADJ_WAVES * 64), 0, (const AdjC *)ctx->d_stage, nt, d_proj, d_vol, g,
+                (const unsigned *)d_absmax, (float)weight_bound);
     return TOMO_OK;
 }
 

@@ -1,0 +1,135 @@
+"""
+SIRT with the constructor / run_main_iteration signature of the reference's recon/sirt.py:7-107,
+running device-resident: `rec`, `b`, `W`, `V`, the residual and the back-projection stay in HBM across
+iterations; per iteration only two scalars cross PCIe.
+
+    W = 1/(A.1), V = 1/(A^T.1)  (0 -> 0)                 recon/sirt.py:33-40
+    rec += V * A^T( W * (b - A rec) ) ; positivity         :59-67
+    rms_error[k] = ||gt - rec||/||gt||  or  ||res||/||b||  :69-73
+    stop when rms_error rises (k > 0)                      :75-78
+
+(The reference's own recon/sirt.py also runs unmodified on this package's operator, through the scipy
+unbound-call protocol of utilities/projection_operators.RayOperator -- tests/test_gpu_solvers.py.)
+"""
+import time
+
+import numpy as np
+
+from .. import _lib
+from ..utilities import projection_operators
+
+
+class SIRT(object):
+
+    def __init__(self, geometry, projections, angles, xyz_shifts, options={}):
+        self.geometry = geometry
+        self.projections = projections
+        self.angles = angles
+        self.xyz_shifts = xyz_shifts
+        self.n_proj = angles.shape[0]
+        self.ground_truth = options['ground_truth'] if 'ground_truth' in options else None
+        self.rec = options['rec'] if 'rec' in options else None
+        if self.rec is None:
+            self.rec = np.zeros((int(self.geometry.n_vox),), dtype=np.asarray(self.projections).dtype)
+        self.precision = options['precision'] if 'precision' in options else np.float32
+        self.voxel_mask = options['voxel_mask'] if 'voxel_mask' in options else None
+        self._backend = options.get('_backend')          # test seam; None -> HipBackend (no CPU fallback)
+        self.f_proj_obj = None
+        self.proj_mat = None
+        # reference quirks that differ between recon/sirt.py and recon/sirt_mpi.py; the sharded subclass flips them
+        self._zero_guard = None      # None: == 0 (sirt.py:37-38) ; float: < thresh (sirt_mpi.py:69-70)
+        self._stop_after = 0         # stop test needs k > 0 (sirt.py:75) / k > 1 (sirt_mpi.py:116)
+        self._initialize()
+
+    # ---- hooks the sharded subclass overrides
+    def _my_rows(self):
+        return np.arange(self.n_proj)
+
+    def _allreduce_vol(self, buf):
+        return buf
+
+    def _allreduce_scalar(self, v):
+        return v
+
+    def _is_root(self):
+        return True
+
+    def _initialize(self):
+        rows = self._my_rows()
+        self._rows = rows
+        if self.f_proj_obj is None:
+            self.f_proj_obj = projection_operators.ProjectionMatrix(self._local_geometry(rows), precision=self.precision,
+                                                                    backend=self._backend)
+            self.proj_mat = self.f_proj_obj.projection_matrix(phi=self.angles[rows, 0], alpha=self.angles[rows, 1],
+                                                              beta=self.angles[rows, 2], xyz_shift=self.xyz_shifts[rows],
+                                                              voxel_mask=self.voxel_mask)
+        be = self.be = self.f_proj_obj.backend
+        n_vox, n_rows = be.n_vox, rows.size * be.n_det
+        ones_v = be.empty(n_vox)
+        be.fill(ones_v, 1.0)
+        self.d_W = self.proj_mat.apply(ones_v, be.empty(n_rows))                 # sirt.py:33
+        ones_p = be.empty(n_rows)
+        be.fill(ones_p, 1.0)
+        self.d_V = self._allreduce_vol(self.proj_mat.T.apply(ones_p, ones_v))    # sirt.py:34 ; sirt_mpi.py:68
+        be.recip_guard(self.d_V, self._zero_guard)                               # sirt.py:37-40
+        be.recip_guard(self.d_W, self._zero_guard)
+        self.d_res = ones_p                                                      # scratch [n_rows]
+        self.d_ax = be.empty(n_rows)
+        self.d_bp = be.empty(n_vox)
+        self.d_rec = be.upload(np.asarray(self.rec, np.float32).ravel())
+        self.d_b = None
+        self.d_gt = None
+
+    def _local_geometry(self, rows):
+        return self.geometry
+
+    @property
+    def W(self):
+        return self.be.download(self.d_W)
+
+    @property
+    def V(self):
+        return self.be.download(self.d_V)
+
+    def run_main_iteration(self, niter=100, make_plot=False, projections=None, positivity=False, debug=False):
+        be = self.be
+        if projections is not None:
+            self.projections = projections
+            self.d_b = None
+        b_all = np.asarray(self.projections, np.float32).reshape(self.n_proj, -1)
+        if self.d_b is None:
+            self.d_b = be.upload(b_all[self._rows])
+        if self.ground_truth is not None:
+            self.ground_truth = np.asarray(self.ground_truth).ravel()
+            norm_factor = np.linalg.norm(self.ground_truth)
+            if self.d_gt is None:
+                self.d_gt = be.upload(self.ground_truth.astype(np.float32))
+        else:
+            norm_factor = np.linalg.norm(b_all)
+        if make_plot:
+            print('make_plot is not supported on the device-resident solver; ignoring')
+
+        stop, k = 0, 0
+        rms_error = np.zeros((niter,))
+        convergence = np.zeros((niter,))
+        t_start = time.time()
+        while k < niter and not stop:
+            self.proj_mat.apply(self.d_rec, self.d_ax)                                  # sirt.py:59
+            sumsq = be.residual_scale(self.d_b, self.d_ax, self.d_W, self.d_res)        # :60-61 (W * res) and :69
+            self.proj_mat.T.apply(self.d_res, self.d_bp)                                # :61
+            be.mul(self.d_bp, self.d_V)                                                 # :63   (sirt_mpi.py:101)
+            self._allreduce_vol(self.d_bp)                                              # sirt_mpi.py:102-103
+            err = be.update(self.d_rec, self.d_bp, None, positivity, self.d_gt)         # :64-67,73
+            convergence[k] = np.sqrt(self._allreduce_scalar(sumsq))                     # :69 ; sirt_mpi.py:110
+            rms_error[k] = convergence[k] / norm_factor if self.ground_truth is None else np.sqrt(err) / norm_factor
+            if k > self._stop_after and rms_error[k] > rms_error[k - 1]:
+                stop = 1
+                if self._is_root():
+                    print('semi-convergence criterion reached: stopping at k %3d with RMSE = %4.5f' % (k, rms_error[k]))
+            if k > 0 and k % 20 == 0 and debug:
+                print('time taken for 20 SIRT iterations = %4.5f' % (time.time() - t_start))
+                t_start = time.time()
+            k += 1
+        self.rec = be.download(self.d_rec)
+        self.rms_error = rms_error
+        return self.rec.reshape(tuple(int(v) for v in self.geometry.vox_shape)), rms_error[:k]

@@ -171,8 +171,10 @@ class ProjectionMatrix(object):
         self.xyz_shift = xyz_shift
         self.voxel_mask = voxel_mask
         cor = np.asarray(self.geometry.cor_shift, np.float64)
-        if cor.ndim == 2 and cor.shape[0] != n_proj:
-            raise ValueError("geometry.cor_shift has %d rows for %d projections" % (cor.shape[0], n_proj))
+        if cor.ndim == 2:
+            if cor.shape[0] < n_proj:
+                raise ValueError("geometry.cor_shift has %d rows for %d projections" % (cor.shape[0], n_proj))
+            cor = cor[:n_proj]      # the reference indexes cor_shift[iproj] (utilities/projection_operators.py:102)
         poses = _lib.poses_array(phi, alpha, beta, xyz_shift, cor)
         return RayOperator(self.backend, poses, self.precision, voxel_mask)
 
