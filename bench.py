@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of BASELINE.json: SIRT iterations/s on a 1024^3 volume x 1024 angles
+(parallel beam, Shepp-Logan, phi = linspace(0, pi)), with the forward / back-projection kernels priced
+against the MI355X HBM roofline.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment; torch is not imported).
+A "step" is one SIRT iteration: A.rec, residual, A^T(W*res), all-reduce of the voxel update over the
+angle shards (RCCL over xGMI; strong scaling: the 1024 angles are split across the N GPUs), update.
+Inputs are resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line ("Measurement"):
+  roofline     dominant kernel of the step: algorithmic bytes per launch / mean launch time (HIP events
+               recorded on the kernel's own stream inside the timed region) against 8 TB/s
+  cpu_baseline the CPU oracle (oracle/: plain-C port of the reference algorithm, 1 thread) timed on this
+               box's host cores on ONE angle of the same workload, extrapolated linearly in n_proj
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1024, help="volume edge N (N^3 voxels, N x N detector)")
+    ap.add_argument("--angles", type=int, default=1024)
+    ap.add_argument("--perturbed", action="store_true", help="alpha,beta ~ U(+-1 deg), tx,tz ~ U(+-2 px) (default_rng(0))")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fwd-variant", type=int, default=None)
+    ap.add_argument("--adj-variant", type=int, default=None)
+    args = ap.parse_args()
+
+    from tomography_alignment_amd import _lib
+    from tomography_alignment_amd.backend import HipBackend
+    from tomography_alignment_amd.comm import RcclComm
+    from tomography_alignment_amd.recon import sirt as sirt_mod, sirt_mpi
+    from tomography_alignment_amd.utilities.geometry import Geometry
+    from tomography_alignment_amd.utilities.generate_phantom import SHEPP_LOGAN
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    N, n_proj = args.size, args.angles
+    comm = RcclComm.from_env()
+    ctx = comm.ctx
+    if args.fwd_variant is not None:
+        ctx.set_option("fwd_variant", args.fwd_variant)
+    if args.adj_variant is not None:
+        ctx.set_option("adj_variant", args.adj_variant)
+
+    geo = Geometry(n_proj, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
+    phi = np.linspace(0., np.pi, n_proj)
+    alpha, beta, xyz = np.zeros(n_proj), np.zeros(n_proj), np.zeros((n_proj, 3))
+    if args.perturbed:
+        rng = np.random.default_rng(0)
+        alpha = np.deg2rad(rng.uniform(-1, 1, n_proj))
+        beta = np.deg2rad(rng.uniform(-1, 1, n_proj))
+        xyz[:, 0] = rng.uniform(-2, 2, n_proj)
+        xyz[:, 2] = rng.uniform(-2, 2, n_proj)
+    angles = np.array([phi, alpha, beta]).T
+
+    # ---- synthetic data, generated and kept on the device: phantom -> this rank's sinogram rows
+    my_rows = np.array_split(np.arange(n_proj), world)[rank]
+    shard_geo = sirt_mpi.SIRT._shard_geometry(geo, my_rows)
+    be = HipBackend(shard_geo, ctx=ctx)
+    d_true = be.phantom(be.empty(N ** 3), (N, N, N), SHEPP_LOGAN)
+    poses = _lib.poses_array(phi[my_rows], alpha[my_rows], beta[my_rows], xyz[my_rows], np.zeros(3))
+    d_b = be.forward(poses, d_true, be.empty(my_rows.size * N * N))
+    opts = {"_backend": be}
+    if world > 1:
+        solver = sirt_mpi.SIRT(comm, geo, d_b, angles, xyz, opts)
+    else:
+        solver = sirt_mod.SIRT(geo, d_b, angles, xyz, opts)
+
+    def barrier():
+        ctx.sync()
+        comm.barrier()
+        ctx.sync()
+
+    if args.warmup > 0:
+        solver.iterate_device(niter=args.warmup)
+    barrier()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    k_done, rms = solver.iterate_device(niter=args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    elapsed = comm.allreduce_max(elapsed)
+    if k_done != args.steps:
+        raise SystemExit("bench.py: solver stopped after %d of %d steps (semi-convergence rule fired)" % (k_done, args.steps))
+
+    # ---- per-kernel timing of the timed region (HIP events on the ctx stream)
+    kern = {}
+    for name in ("k_fwd_v1", "k_fwd_v2", "k_fwd_tile", "k_adj_v1", "k_adj_tile", "k_pad", "k_unpad", "k_absmax", "k_residual_scale", "k_update",
+                 "k_vec", "allreduce_f32"):
+        n, ms = ctx.profile_get(name)
+        if n:
+            kern[name] = {"launches": n, "avg_ms": ms / n}
+    n_loc = my_rows.size
+    n_det = N * N
+    alg_fwd = n_loc * (4.0 * N ** 3 + 4.0 * n_det)               # bytes per forward launch   
+    alg_adj = n_loc * (8.0 * N ** 3 + 4.0 * n_det)               # bytes per back-projection launch
+    fwd_name = next((k for k in ("k_fwd_tile", "k_fwd_v2", "k_fwd_v1") if k in kern), None)
+    adj_name = next((k for k in ("k_adj_tile", "k_adj_v1") if k in kern), None)
+    cands = []
+    if fwd_name:
+        cands.append((kern[fwd_name]["avg_ms"], fwd_name, alg_fwd))
+    if adj_name:
+        cands.append((kern[adj_name]["avg_ms"], adj_name, alg_adj))
+    roofline = None
+    if cands:
+        avg_ms, name, alg = max(cands)
+        ach = alg / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(avg_ms, 3)}
+    extra = {}
+    if fwd_name:
+        extra["forward_alg_GBps"] = round(alg_fwd / (kern[fwd_name]["avg_ms"] * 1e-3) / 1e9, 1)
+    if adj_name:
+        extra["backproj_alg_GBps"] = round(alg_adj / (kern[adj_name]["avg_ms"] * 1e-3) / 1e9, 1)
+
+    its = args.steps / elapsed
+    out = {
+        "metric": "sirt_iterations_per_sec",
+        "value": round(its, 5),
+        "unit": "it/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (3-D Shepp-Logan generated on the device; sinogram = its forward projection)",
+        "config": {"workload": "SIRT %d^3 volume x %d angles, parallel beam, step 1.0, detector %dx%d%s"
+                               % (N, n_proj, N, N, ", perturbed poses" if args.perturbed else ""),
+                   "sharding": "angles split over %d GPU(s), RCCL all-reduce of the voxel update" % world,
+                   "rms_error_last": float(rms[-1])},
+        "roofline": roofline,
+        "kernels": kern,
+    }
+    out.update(extra)
+    if roofline is not None and fwd_name and adj_name:
+        step_alg = n_proj * (12.0 * N ** 3 + 8.0 * n_det) + 16.0 * n_proj * n_det + 16.0 * N ** 3
+        out["sirt_step_alg_GBps"] = round(step_alg / (elapsed / args.steps) / 1e9, 1)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(be, d_true, N, n_proj, phi)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        comm.close()
+
+
+def cpu_baseline(be, d_true, N, n_proj, phi):
+    """Time the CPU oracle (plain-C port of the reference algorithm, serial like the reference's Fortran) on
+    ONE projection angle of the same workload: forward + adjoint; extrapolate linearly to n_proj angles."""
+    from oracle import oracle as orc
+    x = be.download(d_true)
+    og = orc.Geo(1, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
+    ph = np.array([phi[n_proj // 3]])           # a generic (non axis-aligned) angle
+    t0 = time.perf_counter()
+    ax = orc.forward(og, x, phi=ph)
+    t1 = time.perf_counter()
+    orc.adjoint(og, ax.astype(np.float32), phi=ph)
+    t2 = time.perf_counter()
+    per_it = ((t1 - t0) + (t2 - t1)) * n_proj
+    return {"value": round(1.0 / per_it, 8), "unit": "it/s", "cores": 1, "kind": "port",
+            "sample": "1 of %d angles of the same %d^3 workload (forward %.1f s + adjoint %.1f s on one host core), "
+                      "extrapolated linearly in n_proj" % (n_proj, N, t1 - t0, t2 - t1),
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -136,6 +136,11 @@ TOMO_API int tomo_cost_grad(tomo_ctx *ctx, const double *h_poses, int n, const f
 TOMO_API int tomo_triplets(tomo_ctx *ctx, const double *h_pose, int64_t capacity, int32_t *h_dat, int32_t *h_det,
                   double *h_wts, int64_t *n_inds);
 
+/* tomo_phantom_ellipsoids: synthetic test volume (sum of ellipsoid indicator values, clipped at 0) with the
+ *   parametrisation of utilities/generate_phantom.py:81-179,194-209: table rows
+ *   (A, a, b, c, x0, y0, z0, phi, theta, psi), coordinates linspace(-1,1,n) per axis.  bench/test input only. */
+TOMO_API int tomo_phantom_ellipsoids(tomo_ctx *ctx, float *d_vol, int nx, int ny, int nz, const double *h_table, int n_rows);
+
 /* ---------------------------------------------------------------- solver vector kernels
  * (device-resident forms of the numpy lines of recon/sirt.py:33-40,60-73 and recon/cgls.py:56-82) */
 TOMO_API int tomo_vec_recip_guard(tomo_ctx *ctx, float *d_v, int64_t n, float thresh, int strict_zero); /* sirt.py:37-40 / sirt_mpi.py:69-72 */

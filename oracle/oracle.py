@@ -101,8 +101,8 @@ class Geo(object):
         x = np.linspace(-sx / 2, sx / 2, nx, endpoint=False) + 0.5   # geometry.py:82-84
         y = np.linspace(-sy / 2, sy / 2, ny, endpoint=False) + 0.5
         z = np.linspace(-sz / 2, sz / 2, nz, endpoint=False) + 0.5
-        X, Y, Z = np.meshgrid(x, y, z, indexing='ij')
-        self.vox_centers = np.array([X.ravel(), Y.ravel(), Z.ravel()])
+        self._axes = (x, y, z)
+        self._vc = None                      # (3, n_vox) float64 is 25 GB at 1024^3: built on first use
         self.vox_origin = np.array([x.min(), y.min(), z.min()])
         ndx, ndz = self.det_shape
         dsx, dsz = self.det_size
@@ -111,6 +111,14 @@ class Geo(object):
         XD, ZD = np.meshgrid(xd, zd, indexing='ij')
         self.source_centers = np.array([XD.ravel(), -sy * np.ones(self.n_det), ZD.ravel()])
         self.det_centers = np.array([XD.ravel(), sy * np.ones(self.n_det), ZD.ravel()])
+
+
+    @property
+    def vox_centers(self):
+        if self._vc is None:
+            X, Y, Z = np.meshgrid(*self._axes, indexing='ij')     # geometry.py:85-86
+            self._vc = np.array([X.ravel(), Y.ravel(), Z.ravel()])
+        return self._vc
 
 
 # ----------------------------------------------------------------------------------------

@@ -88,6 +88,13 @@ class HipBackend(object):
                                                resid.ptr if resid is not None else None))
         return cost, g6
 
+    def phantom(self, out, shape, table):
+        """Fill `out` with the ellipsoid phantom of utilities/generate_phantom (generated on the device)."""
+        table = np.ascontiguousarray(table, np.float64)
+        nx, ny, nz = (int(v) for v in shape)
+        self.ctx.check(self.lib.tomo_phantom_ellipsoids(self.ctx.handle, out.ptr, nx, ny, nz, _lib.dptr(table), table.shape[0]))
+        return out
+
     # ---- solver vector kernels
     def fill(self, buf, value):
         self.ctx.check(self.lib.tomo_vec_fill(self.ctx.handle, buf.ptr, buf.size, float(value)))

@@ -1,0 +1,124 @@
+"""
+Multi-GPU communicator: RCCL over xGMI through the C-ABI (tomo_comm_* / tomo_allreduce_*), one process
+per GPU.  Replaces the mpi4py COMM_WORLD object the reference's recon/*_mpi.py take as first argument
+(recon/sirt_mpi.py:12,38-39: Get_size / Get_rank; :68,103 Allreduce(SUM); :110 scalar allreduce).
+
+Bootstrap: rank 0 creates the ncclUniqueId and publishes it through a file keyed by the launcher
+(MASTER_PORT + the launcher's pid); the other ranks of the node poll for it.  Launch contract:
+`python -m torch.distributed.run --nproc-per-node N ...` exports RANK / LOCAL_RANK / WORLD_SIZE; this
+module only reads those variables -- it does not import torch.
+"""
+import ctypes
+import os
+import tempfile
+import time
+
+import numpy as np
+
+from . import _lib
+
+
+class SingleComm(object):
+    """World of one: every collective is the identity (the unsharded solvers use this)."""
+    size = 1
+    rank = 0
+
+    def Get_size(self):
+        return 1
+
+    def Get_rank(self):
+        return 0
+
+    def allreduce_sum_(self, buf):
+        return buf
+
+    def allreduce_scalar(self, v):
+        return v
+
+    def allreduce_max(self, v):
+        return v
+
+    def barrier(self):
+        pass
+
+
+class RcclComm(object):
+
+    def __init__(self, ctx, rank, size, id_bytes):
+        self.ctx = ctx
+        self.rank = int(rank)
+        self.size = int(size)
+        buf = ctypes.create_string_buffer(bytes(id_bytes), _lib.COMM_ID_BYTES)
+        ctx.check(ctx.lib.tomo_comm_init(ctx.handle, buf, self.size, self.rank))
+
+    # mpi4py-flavoured accessors so reference-style call sites read the same
+    def Get_size(self):
+        return self.size
+
+    def Get_rank(self):
+        return self.rank
+
+    @staticmethod
+    def unique_id(lib=None):
+        lib = lib or _lib.load()
+        buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+        rc = lib.tomo_comm_get_unique_id(buf)
+        if rc != 0:
+            raise _lib.TomoError("tomo_comm_get_unique_id failed: %s" % (lib.tomo_last_error(None) or b"").decode())
+        return buf.raw
+
+    @classmethod
+    def from_env(cls, ctx=None, timeout=300.0):
+        rank = int(os.environ.get("RANK", "0"))
+        size = int(os.environ.get("WORLD_SIZE", "1"))
+        if ctx is None:
+            ctx = _lib.Context(int(os.environ.get("LOCAL_RANK", str(rank))))
+        if size == 1:
+            c = SingleComm()
+            c.ctx = ctx
+            return c
+        key = "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
+        path = os.path.join(tempfile.gettempdir(), "tomo_rccl_%s.id" % key)
+        if rank == 0:
+            uid = cls.unique_id(ctx.lib)
+            tmp = path + ".tmp%d" % os.getpid()
+            with open(tmp, "wb") as f:
+                f.write(uid)
+            os.replace(tmp, path)
+        else:
+            t0 = time.time()
+            while not os.path.exists(path):
+                if time.time() - t0 > timeout:
+                    raise _lib.TomoError("timed out waiting for the RCCL id file %s" % path)
+                time.sleep(0.05)
+            with open(path, "rb") as f:
+                uid = f.read()
+        comm = cls(ctx, rank, size, uid)
+        comm.barrier()
+        if rank == 0:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+        return comm
+
+    def allreduce_sum_(self, buf):
+        """In-place sum of a float32 DeviceArray across ranks (recon/sirt_mpi.py:103)."""
+        self.ctx.check(self.ctx.lib.tomo_allreduce_sum_f32(self.ctx.handle, buf.ptr, buf.size))
+        return buf
+
+    def allreduce_scalar(self, v):
+        a = np.array([v], np.float64)
+        self.ctx.check(self.ctx.lib.tomo_allreduce_sum_f64_host(self.ctx.handle, _lib.dptr(a), 1))
+        return float(a[0])
+
+    def allreduce_max(self, v):
+        a = np.array([v], np.float64)
+        self.ctx.check(self.ctx.lib.tomo_allreduce_max_f64_host(self.ctx.handle, _lib.dptr(a), 1))
+        return float(a[0])
+
+    def barrier(self):
+        self.allreduce_scalar(0.0)
+
+    def close(self):
+        self.ctx.check(self.ctx.lib.tomo_comm_destroy(self.ctx.handle))

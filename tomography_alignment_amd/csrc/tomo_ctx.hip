@@ -469,6 +469,56 @@ extern "C" int tomo_vec_diff_sumsq(tomo_ctx *ctx, const float *a, const float *b
 }
 
 // ------------------------------------------------------------------------------------------------
+// synthetic phantom (bench / test input): utilities/generate_phantom.py:81-179
+// ------------------------------------------------------------------------------------------------
+struct EllC { double A, inv[3], m[3], R[3][3]; };
+
+__global__ __launch_bounds__(256) void k_phantom(float *__restrict__ vol, int nx, int ny, int nz, const EllC *__restrict__ tab, int n_rows)
+{
+    const int iz = blockIdx.x * 256 + threadIdx.x, iy = blockIdx.y, ix = blockIdx.z;
+    if (iz >= nz) return;
+    const double x = nx > 1 ? -1.0 + 2.0 * ix / (nx - 1) : -1.0;
+    const double y = ny > 1 ? -1.0 + 2.0 * iy / (ny - 1) : -1.0;
+    const double z = nz > 1 ? -1.0 + 2.0 * iz / (nz - 1) : -1.0;
+    float acc = 0.f;
+    for (int k = 0; k < n_rows; ++k) {
+        const EllC e = tab[k];
+        double r2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double q = (e.R[a][0] * x + e.R[a][1] * y + e.R[a][2] * z - e.m[a]) * e.inv[a];
+            r2 += q * q;
+        }
+        if (r2 <= 1.0) acc = (float)((double)acc + e.A);
+    }
+    vol[((size_t)ix * ny + iy) * nz + iz] = fmaxf(acc, 0.f);
+}
+
+extern "C" int tomo_phantom_ellipsoids(tomo_ctx *ctx, float *d_vol, int nx, int ny, int nz, const double *h_table, int n_rows)
+{
+    if (!ctx || !d_vol || !h_table || nx < 1 || ny < 1 || nz < 1 || n_rows < 0 || ny > 65535 || nx > 65535)
+        return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_phantom_ellipsoids: bad args");
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = tomo_ensure_stage(ctx, sizeof(EllC) * (size_t)std::max(n_rows, 1));
+    if (rc) return rc;
+    EllC *h = (EllC *)ctx->h_stage;
+    const double d2r = 3.14159265358979323846 / 180.0;
+    for (int k = 0; k < n_rows; ++k) {
+        const double *r = h_table + (size_t)k * 10;
+        h[k].A = r[0];
+        for (int a = 0; a < 3; ++a) { h[k].inv[a] = 1.0 / r[1 + a]; h[k].m[a] = r[4 + a]; }
+        const double cp = cos(r[7] * d2r), sp = sin(r[7] * d2r), ct = cos(r[8] * d2r), st = sin(r[8] * d2r), cs = cos(r[9] * d2r), ss = sin(r[9] * d2r);
+        const double R[3][3] = {{cs * cp - ct * sp * ss, cs * sp + ct * cp * ss, ss * st},
+                                {-ss * cp - ct * sp * cs, -ss * sp + ct * cp * cs, cs * st},
+                                {st * sp, -st * cp, ct}};
+        memcpy(h[k].R, R, sizeof(R));
+    }
+    TOMO_HIP(ctx, hipMemcpyAsync(ctx->d_stage, h, sizeof(EllC) * (size_t)n_rows, hipMemcpyHostToDevice, ctx->stream));
+    TOMO_LAUNCH(ctx, "k_phantom", k_phantom, dim3((nz + 255) / 256, ny, nx), dim3(256), 0, d_vol, nx, ny, nz, (const EllC *)ctx->d_stage, n_rows);
+    return TOMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // RCCL over xGMI: one process per GPU; replaces mpi4py Allreduce (recon/sirt_mpi.py:68,103,110;
 // recon/cgls_mpi.py:55,75-76,98,107).
 // ------------------------------------------------------------------------------------------------

@@ -40,10 +40,14 @@ class CGLS(object):
     def _allreduce_scalar(self, v):
         return v
 
+    def _local_geometry(self, rows):
+        return self.geometry
+
     def _initialize(self):
         rows = self._rows = self._my_rows()
         if self.f_proj_obj is None:
-            self.f_proj_obj = projection_operators.ProjectionMatrix(self.geometry, precision=self.precision, backend=self._backend)
+            self.f_proj_obj = projection_operators.ProjectionMatrix(self._local_geometry(rows), precision=self.precision,
+                                                                    backend=self._backend)
             self.proj_mat = self.f_proj_obj.projection_matrix(phi=self.angles[rows, 0], alpha=self.angles[rows, 1],
                                                               beta=self.angles[rows, 2], xyz_shift=self.xyz_shift[rows])
         be = self.be = self.f_proj_obj.backend

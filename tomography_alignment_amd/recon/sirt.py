@@ -29,8 +29,9 @@ class SIRT(object):
         self.n_proj = angles.shape[0]
         self.ground_truth = options['ground_truth'] if 'ground_truth' in options else None
         self.rec = options['rec'] if 'rec' in options else None
+        self._rec_given = self.rec is not None
         if self.rec is None:
-            self.rec = np.zeros((int(self.geometry.n_vox),), dtype=np.asarray(self.projections).dtype)
+            self.rec = np.zeros((int(self.geometry.n_vox),), dtype=getattr(self.projections, 'dtype', np.float32))
         self.precision = options['precision'] if 'precision' in options else np.float32
         self.voxel_mask = options['voxel_mask'] if 'voxel_mask' in options else None
         self._backend = options.get('_backend')          # test seam; None -> HipBackend (no CPU fallback)
@@ -76,7 +77,10 @@ class SIRT(object):
         self.d_res = ones_p                                                      # scratch [n_rows]
         self.d_ax = be.empty(n_rows)
         self.d_bp = be.empty(n_vox)
-        self.d_rec = be.upload(np.asarray(self.rec, np.float32).ravel())
+        if not self._rec_given:
+            self.d_rec = be.zeros(n_vox)              # zero start (sirt.py:18-19) without a host round trip
+        else:
+            self.d_rec = self.rec if be.is_buffer(self.rec) else be.upload(np.asarray(self.rec, np.float32).ravel())
         self.d_b = None
         self.d_gt = None
 
@@ -91,24 +95,35 @@ class SIRT(object):
     def V(self):
         return self.be.download(self.d_V)
 
-    def run_main_iteration(self, niter=100, make_plot=False, projections=None, positivity=False, debug=False):
+    def _prepare(self, projections=None):
         be = self.be
         if projections is not None:
             self.projections = projections
             self.d_b = None
-        b_all = np.asarray(self.projections, np.float32).reshape(self.n_proj, -1)
-        if self.d_b is None:
-            self.d_b = be.upload(b_all[self._rows])
+        if be.is_buffer(self.projections):              # already in HBM (this rank's rows): no PCIe traffic
+            if self.d_b is None:
+                self.d_b = self.projections
+            b_sumsq = self._allreduce_scalar(be.dot(self.d_b, self.d_b))
+        else:
+            b_all = np.asarray(self.projections, np.float32).reshape(self.n_proj, -1)
+            if self.d_b is None:
+                self.d_b = be.upload(b_all[self._rows])
+            b_sumsq = float(np.linalg.norm(b_all)) ** 2
         if self.ground_truth is not None:
+            if be.is_buffer(self.ground_truth):
+                self.d_gt = self.ground_truth
+                return np.sqrt(be.dot(self.d_gt, self.d_gt))
             self.ground_truth = np.asarray(self.ground_truth).ravel()
-            norm_factor = np.linalg.norm(self.ground_truth)
             if self.d_gt is None:
                 self.d_gt = be.upload(self.ground_truth.astype(np.float32))
-        else:
-            norm_factor = np.linalg.norm(b_all)
-        if make_plot:
-            print('make_plot is not supported on the device-resident solver; ignoring')
+            return np.linalg.norm(self.ground_truth)                                   # sirt.py:47-49
+        return np.sqrt(b_sumsq)                                                        # sirt.py:51
 
+    def iterate_device(self, niter=100, positivity=False, projections=None, debug=False):
+        """The loop of recon/sirt.py:58-105 with every vector in HBM; returns (k, rms_error[:k]).
+        `self.d_rec` holds the reconstruction afterwards."""
+        be = self.be
+        norm_factor = self._prepare(projections)
         stop, k = 0, 0
         rms_error = np.zeros((niter,))
         convergence = np.zeros((niter,))
@@ -121,7 +136,7 @@ class SIRT(object):
             self._allreduce_vol(self.d_bp)                                              # sirt_mpi.py:102-103
             err = be.update(self.d_rec, self.d_bp, None, positivity, self.d_gt)         # :64-67,73
             convergence[k] = np.sqrt(self._allreduce_scalar(sumsq))                     # :69 ; sirt_mpi.py:110
-            rms_error[k] = convergence[k] / norm_factor if self.ground_truth is None else np.sqrt(err) / norm_factor
+            rms_error[k] = convergence[k] / norm_factor if self.d_gt is None else np.sqrt(err) / norm_factor
             if k > self._stop_after and rms_error[k] > rms_error[k - 1]:
                 stop = 1
                 if self._is_root():
@@ -130,6 +145,13 @@ class SIRT(object):
                 print('time taken for 20 SIRT iterations = %4.5f' % (time.time() - t_start))
                 t_start = time.time()
             k += 1
-        self.rec = be.download(self.d_rec)
         self.rms_error = rms_error
-        return self.rec.reshape(tuple(int(v) for v in self.geometry.vox_shape)), rms_error[:k]
+        self.convergence = convergence
+        return k, rms_error[:k]
+
+    def run_main_iteration(self, niter=100, make_plot=False, projections=None, positivity=False, debug=False):
+        if make_plot:
+            print('make_plot is not supported on the device-resident solver; ignoring')
+        k, rms = self.iterate_device(niter=niter, positivity=positivity, projections=projections, debug=debug)
+        self.rec = self.be.download(self.d_rec)
+        return self.rec.reshape(tuple(int(v) for v in self.geometry.vox_shape)), rms
