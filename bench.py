@@ -133,6 +133,15 @@ def main():
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(avg_ms, 3)}
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (counters cannot be
+        # collected from inside the timed run; see profiles/*_rocprof_summary.md for how they were taken/corrected)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pmc.get("key") == "N%d_A%d_G%d%s" % (N, n_proj, world, "_P" if args.perturbed else "") and name in pmc["kernels"]:
+                roofline["traffic"] = pmc["kernels"][name]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/pmc_traffic.json (%s)" % pmc.get("source", "")
+        except (OSError, ValueError, KeyError):
+            pass
     extra = {}
     if fwd_name:
         extra["forward_alg_GBps"] = round(alg_fwd / (kern[fwd_name]["avg_ms"] * 1e-3) / 1e9, 1)

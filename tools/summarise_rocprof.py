@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (kernel-trace --stats CSV, --pmc CSVs) into the small tracked files under
+profiles/.  Usage:
+  tools/summarise_rocprof.py TAG STATS_DIR [FETCH_DIR WRITE_DIR] --workload "N=1024 n_proj=1024 n_gpus=1"
+HBM bytes follow MI355X_MICROARCH.md (HBM / rocprofv3): counters are in KB; on gfx950 FETCH_SIZE counts
+exactly 1/2 of coalesced reads (re-calibrated here on kernels with a known byte count: k_pad, k_absmax,
+k_dot read 4 GiB and report 2.097e6 KB), WRITE_SIZE is exact:  bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024."""
+import argparse
+import csv
+import glob
+import json
+import os
+
+
+def find(d, pat):
+    m = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+    return m[0] if m else None
+
+
+def pmc(d, name):
+    out = {}
+    if not d:
+        return out
+    path = find(d, "*counter_collection.csv")
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == name:
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            out.setdefault(k, []).append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tag")
+    ap.add_argument("stats_dir")
+    ap.add_argument("fetch_dir", nargs="?")
+    ap.add_argument("write_dir", nargs="?")
+    ap.add_argument("--workload", default="")
+    ap.add_argument("--out", default="profiles")
+    ap.add_argument("--key", default="", help="workload key bench.py matches, e.g. N1024_A1024_G1")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    rows = list(csv.DictReader(open(find(a.stats_dir, "*kernel_stats.csv"))))
+    fetch, write = pmc(a.fetch_dir, "FETCH_SIZE"), pmc(a.write_dir, "WRITE_SIZE")
+    lines = ["# rocprofv3 summary `%s`" % a.tag, "", "workload: %s" % a.workload, "",
+             "## `rocprofv3 --kernel-trace --stats -- python3 bench.py ...`", "",
+             "| kernel | calls | avg ms | total ms | % |", "|---|---|---|---|---|"]
+    for r in rows:
+        lines.append("| `%s` | %s | %.3f | %.1f | %s |" % (r["Name"].split("(")[0].replace("void ", ""), r["Calls"], float(r["AverageNs"]) / 1e6,
+                                                          float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+    traffic = {}
+    if fetch or write:
+        lines += ["", "## PMC passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, separate runs; per launch, max over launches)", "",
+                  "| kernel | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes/launch = (2*F + W)*1024 |", "|---|---|---|---|"]
+        for k in sorted(set(fetch) | set(write)):
+            f = max(fetch.get(k, [0.0]))
+            w = max(write.get(k, [0.0]))
+            b = (2.0 * f + w) * 1024.0
+            if b < 1e6:
+                continue
+            traffic[k] = {"fetch_kb": f, "write_kb": w, "hbm_bytes_per_launch": b}
+            lines.append("| `%s` | %.4g | %.4g | %.4g |" % (k, f, w, b))
+    open(os.path.join(a.out, a.tag + "_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
+    if traffic:
+        json.dump({"workload": a.workload, "key": a.key, "source": a.tag, "kernels": traffic}, open(os.path.join(a.out, "pmc_traffic.json"), "w"), indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
