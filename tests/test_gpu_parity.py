@@ -33,7 +33,7 @@ def PM():
     return ProjectionMatrix
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_forward_adjoint_vs_reference_golden(PM, shepp32, variant):
     g = golden("g2_fwd_adj")
     geo, _ = geo_pair(6, 32)
@@ -49,7 +49,7 @@ def test_forward_adjoint_vs_reference_golden(PM, shepp32, variant):
     A0 = P.projection_matrix()          # unperturbed poses (phi = 0, pi/2, pi among them: integer coordinates)
     assert rel_max(A0.dot(shepp32.ravel()), g["Ax0"]) < TOL
     assert rel_max(A0.T.dot(g["y"].ravel()), g["ATy0"]) < TOL
-    P.backend.ctx.set_option("fwd_variant", 2)
+    P.backend.ctx.set_option("fwd_variant", 3)
 
 
 def test_scipy_unbound_protocol(PM, shepp32):
@@ -153,18 +153,19 @@ def test_cost_grad_fused_vs_oracle(PM, orc, shepp32):
     rng = np.random.default_rng(4)
     n = 3
     b = np.zeros((n, 1024), np.float32)
-    want_c, want_g = [], []
+    want_c, want_g, scale_g = [], [], []
     for i in range(n):
         p, gr = orc.projection_gradient(og, shepp32, g["alpha"][i], g["beta"][i], g["phi"][i], g["xyz"][i], g["cor"][i])
         b[i] = p + 0.05 * rng.standard_normal(1024).astype(np.float32)
         res = b[i].astype(np.float64) - p
         want_c.append(0.5 * np.dot(res, res))
         want_g.append(np.dot(-gr.astype(np.float64), res))
+        scale_g.append(np.dot(np.abs(gr.astype(np.float64)), np.abs(res)))     # size of the terms the reduction cancels
     poses = _lib.poses_array(g["phi"][:n], g["alpha"][:n], g["beta"][:n], g["xyz"][:n], g["cor"][:n])
     resid = be.empty(n * 1024)
     cost, g6 = be.cost_grad(poses, be.upload(shepp32), be.upload(b), resid)
     assert np.allclose(cost, want_c, rtol=1e-5)
-    assert rel_max(g6, np.array(want_g)) < TOL
+    assert np.max(np.abs(g6 - np.array(want_g)) / np.array(scale_g)) < TOL
     r = resid.download().reshape(n, -1)
     assert rel_max(r[0], b[0] - orc.projection_gradient(og, shepp32, g["alpha"][0], g["beta"][0], g["phi"][0], g["xyz"][0], g["cor"][0])[0]) < 1e-4
 
@@ -222,9 +223,10 @@ def test_properties_at_256(PM):
     rhs = np.dot(x1.astype(np.float64), ATy.astype(np.float64))
     assert abs(lhs - rhs) / abs(lhs) < 1e-5
     assert rel_max(A.dot(x1 + 2 * x2), Ax1 + 2 * Ax2) < TOL
-    P.backend.ctx.set_option("fwd_variant", 1)
-    assert rel_max(A.dot(x1), Ax1) < 1e-6
-    P.backend.ctx.set_option("fwd_variant", 2)
+    for v in (1, 2):
+        P.backend.ctx.set_option("fwd_variant", v)
+        assert rel_max(A.dot(x1), Ax1) < 2e-6
+    P.backend.ctx.set_option("fwd_variant", 3)
     # row sums of a ray through the full volume ~ path length: every central ray of an axis-aligned view crosses N voxels
     A0 = P.projection_matrix(phi=np.array([0.0]))
     ones = A0.dot(np.ones(N ** 3, np.float32)).reshape(N, N)

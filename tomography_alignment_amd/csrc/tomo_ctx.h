@@ -38,8 +38,8 @@ struct tomo_ctx {
     double *h_red = nullptr;
     size_t red_cap = 0;     // doubles
     // options
-    int fwd_variant = 2;
-    int adj_variant = 2;
+    int fwd_variant = 3;      // 1 ray-driven plain, 2 ray-driven SGPR-base, 3 LDS tile (default)
+    int adj_variant = 2;      // 1 global float atomics, 2 LDS tile fixed-point (default)
     int adj_batch = 0;      // 0 = auto
     // timing / profiling
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

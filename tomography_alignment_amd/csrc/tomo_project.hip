@@ -301,82 +301,112 @@ __device__ __forceinline__ int cvt_round_i32(float x)
     return r;
 }
 
-__global__ __launch_bounds__(ADJ_WAVES * 64) void k_adj_tile(const AdjC *__restrict__ pcs, int n_proj, const float *__restrict__ proj,
-                                                             float *__restrict__ vol, TomoGeomC g, const unsigned *__restrict__ absmax_bits,
-                                                             float weight_bound)
+// FWD = true : the LDS image holds the volume tile (+1 high-side halo, zeros outside the volume); owned samples are
+//              interpolated from it with ds_read and each (tile, projection, detector row) adds its partial ray sums to
+//              proj with one 256-B global float atomic per wave -- the volume is read from HBM once per CALL, not per angle.
+// FWD = false: the adjoint described above.
+template <bool FWD>
+__global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
+                                                         float *__restrict__ vol, TomoGeomC g, const unsigned *__restrict__ absmax_bits,
+                                                         float weight_bound)
 {
     __shared__ int acc[ALX * ALY * ALZ];
+    const float *img = (const float *)acc;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int z0 = -1 + (int)blockIdx.x * ATZ, y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + (int)blockIdx.z * ATX;
-    const float ymax = __uint_as_float(*absmax_bits);
-    if (!(ymax > 0.f)) return;                                   // A^T 0 = 0 (vol already holds the right answer)
-    // |image| <= ADJ_BATCH * ymax * weight_bound  ->  keep it below 2^30
-    const float scale = 1073741824.f / ((float)min(n_proj, ADJ_BATCH) * ymax * weight_bound);
-    const float inv_scale = 1.f / scale;
-    for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) acc[e] = 0;
-    __syncthreads();
+    float scale = 1.f, inv_scale = 1.f;
+    if (FWD) {
+        bool any_nz = false;
+        for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) {
+            const int lz = e % ALZ, t2 = e / ALZ, ly = t2 % ALY, lx = t2 / ALY;
+            const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
+            float v = 0.f;
+            if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz) v = vol[((size_t)gx * g.ny + gy) * g.nz + gz];
+            ((float *)acc)[e] = v;
+            any_nz |= (v != 0.f);
+        }
+        if (!__syncthreads_or(any_nz)) return;                   // an all-zero tile contributes nothing to any ray
+    } else {
+        const float ymax = __uint_as_float(*absmax_bits);
+        if (!(ymax > 0.f)) return;                               // A^T 0 = 0 (vol already holds the right answer)
+        // |image| <= ADJ_BATCH * ymax * weight_bound  ->  keep it below 2^30
+        scale = 1073741824.f / ((float)min(n_proj, ADJ_BATCH) * ymax * weight_bound);
+        inv_scale = 1.f / scale;
+        for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) acc[e] = 0;
+        __syncthreads();
+    }
     const double blo[3] = {(double)x0, (double)y0, (double)z0};
     const double bhi[3] = {(double)(x0 + ATX), (double)(y0 + ATY), (double)(z0 + ATZ)};
     const size_t n_det = (size_t)g.ndx * g.ndz;
 
-    for (int ip0 = 0; ip0 < n_proj; ip0 += ADJ_BATCH) {
-        const int ip1 = min(n_proj, ip0 + ADJ_BATCH);
+    const int batch = FWD ? n_proj : ADJ_BATCH;
+    for (int ip0 = 0; ip0 < n_proj; ip0 += batch) {
+        const int ip1 = min(n_proj, ip0 + batch);
         for (int ip = ip0; ip < ip1; ++ip) {
             const AdjC &c = pcs[ip];
-            // lattice-coordinate ranges of the owned box (linear functionals: extremes at the 8 corners)
-            double ixl = 1e300, ixh = -1e300, izl = 1e300, izh = -1e300;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const double qx = ((k & 1) ? bhi[0] : blo[0]) - c.p0[0];
-                const double qy = ((k & 2) ? bhi[1] : blo[1]) - c.p0[1];
-                const double qz = ((k & 4) ? bhi[2] : blo[2]) - c.p0[2];
-                const double fi = c.minv[0][0] * qx + c.minv[0][1] * qy + c.minv[0][2] * qz;
-                const double fz = c.minv[1][0] * qx + c.minv[1][1] * qy + c.minv[1][2] * qz;
-                ixl = fmin(ixl, fi); ixh = fmax(ixh, fi);
-                izl = fmin(izl, fz); izh = fmax(izh, fz);
-            }
-            const int ix_lo = max(0, (int)ceil(fmax(ixl, -1.0) - 1e-6));
-            const int ix_hi = min(g.ndx - 1, (int)floor(fmin(ixh, (double)g.ndx) + 1e-6));
+            // lattice-coordinate ranges of the owned box: a linear functional over a box = centre value +- sum |coef|*half-extent
+            const double qx = 0.5 * (blo[0] + bhi[0]) - c.p0[0], qy = 0.5 * (blo[1] + bhi[1]) - c.p0[1], qz = 0.5 * (blo[2] + bhi[2]) - c.p0[2];
+            const double ixc = c.minv[0][0] * qx + c.minv[0][1] * qy + c.minv[0][2] * qz;
+            const double ixr = fabs(c.minv[0][0]) * (0.5 * ATX) + fabs(c.minv[0][1]) * (0.5 * ATY) + fabs(c.minv[0][2]) * (0.5 * ATZ);
+            const double izm = c.minv[1][0] * qx + c.minv[1][1] * qy + c.minv[1][2] * qz;
+            const double izr = fabs(c.minv[1][0]) * (0.5 * ATX) + fabs(c.minv[1][1]) * (0.5 * ATY) + fabs(c.minv[1][2]) * (0.5 * ATZ);
+            const int ix_lo = max(0, (int)ceil(fmax(ixc - ixr, -1.0) - 1e-6));
+            const int ix_hi = min(g.ndx - 1, (int)floor(fmin(ixc + ixr, (double)g.ndx) + 1e-6));
             if (ix_lo > ix_hi) continue;
-            izl = fmax(izl, 0.0);
-            izh = fmin(izh, (double)(g.ndz - 1));
+            const double izl = fmax(izm - izr, 0.0), izh = fmin(izm + izr, (double)(g.ndz - 1));
             if (izl > izh + 1.0) continue;
             const double izc = 0.5 * (izl + izh), hs = 0.5 * (izh - izl) + 1.0;   // lanes' iz spread about the centre line
             const float dxf = (float)c.d[0], dyf = (float)c.d[1], dzf = (float)c.d[2];
+            const int n_rows_w = (ix_hi - ix_lo - wv) >= 0 ? (ix_hi - ix_lo - wv) / ADJ_WAVES + 1 : 0;   // this wave's rows
 
-            for (int ix = ix_lo + wv; ix <= ix_hi; ix += ADJ_WAVES) {
-                // sample range of this detector row: centre line clipped against the box widened by the lanes' spread
-                double t0 = 0.0, t1 = (double)(c.n - 1);
+            for (int r0 = 0; r0 < n_rows_w; r0 += 64) {
+                // row set-up, one detector row per LANE (row r0+lane of this wave), broadcast below with v_readlane:
+                // sample range = centre line clipped against the box widened by the lanes' lateral spread; detector-z
+                // lanes needed for ownership in z over that range
+                int v_jlo = 0, v_jhi = 0, v_izf = 0, v_izl = -1;
+                {
+                    const int rix = ix_lo + wv + ADJ_WAVES * (r0 + lane);
+                    double t0 = 0.0, t1 = (double)(c.n - 1);
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const double cb = c.p0[a] + (double)ix * c.u[a] + izc * c.w[a];
-                    const double h = fabs(c.w[a]) * hs + 1e-5;
-                    tomo_clip_axis(cb, c.d[a], blo[a] - h, bhi[a] + h, t0, t1);
+                    for (int a = 0; a < 3; ++a) {
+                        const double cb = c.p0[a] + (double)rix * c.u[a] + izc * c.w[a];
+                        const double h = fabs(c.w[a]) * hs + 1e-5;
+                        tomo_clip_axis(cb, c.d[a], blo[a] - h, bhi[a] + h, t0, t1);
+                    }
+                    if (rix <= ix_hi && t0 <= t1) {
+                        v_jlo = max(0, (int)ceil(t0 - 1e-6));
+                        v_jhi = min(c.n, (int)floor(t1 + 1e-6) + 1);
+                        const double cz = c.p0[2] + (double)rix * c.u[2];
+                        const double zj0 = (double)v_jlo * c.d[2], zj1 = (double)(v_jhi - 1) * c.d[2];
+                        const double iw = 1.0 / c.w[2];
+                        v_izf = max(0, (int)floor((blo[2] - cz - fmax(zj0, zj1)) * iw - 1e-5));
+                        v_izl = min(g.ndz - 1, (int)ceil((bhi[2] - cz - fmin(zj0, zj1)) * iw + 1e-5));
+                    }
                 }
-                if (!(t0 <= t1)) continue;
-                const int jlo = max(0, (int)ceil(t0 - 1e-6)), jhi = min(c.n, (int)floor(t1 + 1e-6) + 1);
+                const int r_end = min(64, n_rows_w - r0);
+                for (int r = 0; r < r_end; ++r) {
+                const int jlo = __builtin_amdgcn_readlane(v_jlo, r), jhi = __builtin_amdgcn_readlane(v_jhi, r);
                 if (jhi <= jlo) continue;
-                // detector-z lanes needed for ownership in z over j in [jlo, jhi)
-                const double cz = c.p0[2] + (double)ix * c.u[2];
-                const double zj0 = (double)jlo * c.d[2], zj1 = (double)(jhi - 1) * c.d[2];
-                const double zjmin = fmin(zj0, zj1), zjmax = fmax(zj0, zj1);
-                const int iz_first = max(0, (int)floor((blo[2] - cz - zjmax) / c.w[2] - 1e-5));
-                const int iz_last = min(g.ndz - 1, (int)ceil((bhi[2] - cz - zjmin) / c.w[2] + 1e-5));
+                const int iz_first = __builtin_amdgcn_readlane(v_izf, r), iz_last = __builtin_amdgcn_readlane(v_izl, r);
+                const int ix = ix_lo + wv + ADJ_WAVES * (r0 + r);
                 for (int izb = iz_first; izb <= iz_last; izb += 64) {
                     const int iz = izb + lane;
                     const bool lane_ok = iz <= iz_last;
                     const int izk = lane_ok ? iz : iz_last;
-                    const float ys = (lane_ok ? proj[(size_t)ip * n_det + (size_t)ix * g.ndz + izk] : 0.f) * scale;
+                    float *pr = proj + (size_t)ip * n_det + (size_t)ix * g.ndz + izk;
+                    const float ys = FWD ? 0.f : (lane_ok ? *pr : 0.f) * scale;
+                    float part = 0.f;
+                    bool touched = false;
                     double b[3];
 #pragma unroll
                     for (int a = 0; a < 3; ++a) b[a] = c.p0[a] + (double)ix * c.u[a] + (double)izk * c.w[a];
-                    for (int jb = jlo & ~(TOMO_JB - 1); jb < jhi; jb += TOMO_JB) {
+                    for (int jb = jlo & ~(TOMO_TILE_JB - 1); jb < jhi; jb += TOMO_TILE_JB) {
                         int ia[3];
                         float f0[3];
-                        tomo_block_anchor(b, c.d, jb, ia, f0);          // tile-independent: same bits in every tile
+                        tomo_block_anchor(b, c.d, jb, ia, f0, TOMO_TILE_JB);   // tile-independent: same bits in every tile
                         const int ox = ia[0] - x0, oy = ia[1] - y0, oz = ia[2] - z0;
-                        const int lo = max(jlo, jb) - jb, hi = min(jhi, jb + TOMO_JB) - jb;
+                        const int lo = max(jlo, jb) - jb, hi = min(jhi, jb + TOMO_TILE_JB) - jb;
                         for (int jj = lo; jj < hi; ++jj) {
                             const float t = (float)jj;
                             const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
@@ -384,6 +414,13 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_adj_tile(const AdjC *__restr
                             const int lx = ox + (int)fx, ly = oy + (int)fy, lz = oz + (int)fz;
                             if (lane_ok && (unsigned)lx < (unsigned)ATX && (unsigned)ly < (unsigned)ATY && (unsigned)lz < (unsigned)ATZ) {
                                 const float wcx = x - fx, wcy = y - fy, wcz = z - fz;
+                                if (FWD) {
+                                    const float *q = &img[(int)(__umul24((unsigned)lx, ALY) + (unsigned)ly) * ALZ + lz];
+                                    part += trilerp(q[0], q[1], q[ALZ], q[ALZ + 1], q[ALY * ALZ], q[ALY * ALZ + 1], q[ALY * ALZ + ALZ],
+                                                    q[ALY * ALZ + ALZ + 1], wcx, wcy, wcz);
+                                    touched = true;
+                                    continue;
+                                }
                                 const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
                                 const float a0 = ys * wfx, a1 = ys * wcx;
                                 const float b00 = a0 * wfy, b01 = a0 * wcy, b10 = a1 * wfy, b11 = a1 * wcy;
@@ -399,9 +436,12 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_adj_tile(const AdjC *__restr
                             }
                         }
                     }
+                    if (FWD && touched) atomicAdd(pr, part);          // 64 consecutive floats per wave: the full-rate atomic shape
+                }
                 }
             }
         }
+        if (FWD) break;
         __syncthreads();
         // flush this batch: interior of the image is exclusively ours, the +1 faces are shared => global atomics
         for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) {
@@ -589,15 +629,86 @@ static inline dim3 ray_grid(const TomoGeomC &g, int n_proj) { return dim3((g.ndz
 
 #define TOMO_MAX_GRID_Z 65535
 
+static bool invert3(const double m[3][3], double inv[3][3], double *det_out)
+{
+    const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                       m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+    *det_out = det;
+    if (!(fabs(det) > 1e-12)) return false;
+    const double id = 1.0 / det;
+    inv[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) * id;
+    inv[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * id;
+    inv[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * id;
+    inv[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) * id;
+    inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * id;
+    inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) * id;
+    inv[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) * id;
+    inv[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) * id;
+    inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) * id;
+    return true;
+}
+
+// Per-projection constants of the tile kernels, staged to the device.  Returns false (and stages nothing) when
+// some projection's detector-z axis does not map mostly onto volume z (tilt beyond ~45 deg) or its lattice is
+// singular: those calls take the ray-driven / atomic kernels instead.
+static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, bool *all_ok, double *weight_bound)
+{
+    const TomoGeomC &g = ctx->g;
+    *all_ok = false;
+    *weight_bound = 2.0;
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = tomo_ensure_stage(ctx, sizeof(AdjC) * (size_t)std::max(n_proj, 1));
+    if (rc) return rc;
+    AdjC *h = (AdjC *)ctx->h_stage;
+    for (int i = 0; i < n_proj; ++i) {
+        ProjC pc;
+        tomo_make_projc(g, h_poses + (size_t)i * TOMO_POSE_STRIDE, pc, nullptr);
+        AdjC &a = h[i];
+        double m[3][3], det = 0.0;
+        for (int r = 0; r < 3; ++r) {
+            a.p0[r] = pc.p0[r]; a.u[r] = pc.u[r]; a.w[r] = pc.w[r]; a.d[r] = pc.d[r];
+            m[r][0] = pc.u[r]; m[r][1] = pc.w[r]; m[r][2] = pc.d[r];
+        }
+        a.n = pc.n;
+        a.pad_ = 0;
+        if (!invert3(m, a.minv, &det)) return TOMO_OK;
+        if (!(pc.w[2] > 0.7 * sqrt(pc.w[0] * pc.w[0] + pc.w[1] * pc.w[1] + pc.w[2] * pc.w[2]))) return TOMO_OK;
+        // samples per unit volume = 1/|det[u w d]|; the tent weights a voxel collects from one projection sum to about
+        // that density (exactly 1 for an axis-aligned unit lattice); x2 head-room for the fixed-point image
+        *weight_bound = std::max(*weight_bound, 2.0 / fabs(det));
+    }
+    if (n_proj) TOMO_HIP(ctx, hipMemcpyAsync(ctx->d_stage, h, sizeof(AdjC) * (size_t)n_proj, hipMemcpyHostToDevice, ctx->stream));
+    *all_ok = true;
+    return TOMO_OK;
+}
+
+static inline dim3 tile_grid(const TomoGeomC &g) { return dim3((g.nz + 1 + ATZ - 1) / ATZ, (g.ny + 1 + ATY - 1) / ATY, (g.nx + 1 + ATX - 1) / ATX); }
+
 extern "C" int tomo_forward(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_vol, float *d_proj)
 {
     TOMO_NEED_GEOM(ctx);
     if (!h_poses || !d_vol || !d_proj || n_proj < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_forward: bad args");
     if (n_proj == 0) return TOMO_OK;
     const TomoGeomC &g = ctx->g;
-    int rc = stage_volume(ctx, d_vol);
-    if (rc) return rc;
     const size_t n_det = (size_t)g.ndx * g.ndz;
+    int rc;
+    if (ctx->fwd_variant == 3) {
+        const dim3 grid = tile_grid(g);
+        bool ok = false;
+        double wb = 2.0;
+        if (grid.y <= 65535 && grid.z <= 65535) {
+            rc = stage_tile_consts(ctx, h_poses, n_proj, &ok, &wb);
+            if (rc) return rc;
+        }
+        if (ok) {
+            TOMO_HIP(ctx, hipMemsetAsync(d_proj, 0, n_det * (size_t)n_proj * sizeof(float), ctx->stream));
+            TOMO_LAUNCH(ctx, "k_fwd_tile", k_tile<true>, grid, dim3(ADJ_WAVES * 64), 0, (const AdjC *)ctx->d_stage, n_proj, d_proj,
+                        (float *)d_vol, g, (const unsigned *)nullptr, 1.f);
+            return TOMO_OK;
+        }
+    }
+    rc = stage_volume(ctx, d_vol);
+    if (rc) return rc;
     for (int p0 = 0; p0 < n_proj; p0 += TOMO_MAX_GRID_Z) {
         const int np = std::min(TOMO_MAX_GRID_Z, n_proj - p0);
         ProjC *d_pc = nullptr;
@@ -629,24 +740,6 @@ static int adjoint_atomic(tomo_ctx *ctx, const double *h_poses, int n_proj, cons
     return TOMO_OK;
 }
 
-static bool invert3(const double m[3][3], double inv[3][3])
-{
-    const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
-                       m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
-    if (!(fabs(det) > 1e-12)) return false;
-    const double id = 1.0 / det;
-    inv[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) * id;
-    inv[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * id;
-    inv[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * id;
-    inv[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) * id;
-    inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * id;
-    inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) * id;
-    inv[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) * id;
-    inv[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) * id;
-    inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) * id;
-    return true;
-}
-
 extern "C" int tomo_adjoint(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_proj, float *d_vol, int accumulate)
 {
     TOMO_NEED_GEOM(ctx);
@@ -654,57 +747,22 @@ extern "C" int tomo_adjoint(tomo_ctx *ctx, const double *h_poses, int n_proj, co
     const TomoGeomC &g = ctx->g;
     const size_t n_det = (size_t)g.ndx * g.ndz;
     const size_t n_vox = (size_t)g.nx * g.ny * g.nz;
-    if (ctx->adj_variant == 1) return adjoint_atomic(ctx, h_poses, n_proj, d_proj, d_vol, accumulate);
-
-    // tile kernel for projections whose detector-z axis maps mostly onto volume z (any ordinary tomography
-    // pose); the rest (tilt beyond ~45 deg) takes the atomic path.
-    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    int rc = tomo_ensure_stage(ctx, sizeof(AdjC) * (size_t)std::max(n_proj, 1));
-    if (rc) return rc;
-    AdjC *h = (AdjC *)ctx->h_stage;
-    std::vector<double> rest;        // poses for the atomic path
-    std::vector<int> rest_idx;
-    std::vector<int> tile_idx;
-    int nt = 0;
+    const dim3 grid = tile_grid(g);
+    bool ok = false;
     double weight_bound = 2.0;
-    for (int i = 0; i < n_proj; ++i) {
-        ProjC pc;
-        tomo_make_projc(g, h_poses + (size_t)i * TOMO_POSE_STRIDE, pc, nullptr);
-        AdjC a;
-        double m[3][3];
-        for (int r = 0; r < 3; ++r) {
-            a.p0[r] = pc.p0[r]; a.u[r] = pc.u[r]; a.w[r] = pc.w[r]; a.d[r] = pc.d[r];
-            m[r][0] = pc.u[r]; m[r][1] = pc.w[r]; m[r][2] = pc.d[r];
-        }
-        a.n = pc.n;
-        a.pad_ = 0;
-        const bool ok = invert3(m, a.minv) && pc.w[2] > 0.7 * sqrt(pc.w[0] * pc.w[0] + pc.w[1] * pc.w[1] + pc.w[2] * pc.w[2]);
-        if (ok) {
-            // samples per unit volume = 1/|det[u w d]|; the tent weights a voxel collects from one projection sum to about
-            // that density (exactly 1 for an axis-aligned unit lattice); x2 head-room
-            const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
-                               m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
-            weight_bound = std::max(weight_bound, 2.0 / fabs(det));
-        }
-        if (ok) { h[nt++] = a; tile_idx.push_back(i); }
-        else { rest_idx.push_back(i); }
+    if (ctx->adj_variant != 1 && n_proj > 0 && grid.y <= 65535 && grid.z <= 65535) {
+        int rc = stage_tile_consts(ctx, h_poses, n_proj, &ok, &weight_bound);
+        if (rc) return rc;
     }
-    if (!rest_idx.empty() && !tile_idx.empty()) {
-        // mixed call: keep it simple and exact -- everything through the atomic path
-        return adjoint_atomic(ctx, h_poses, n_proj, d_proj, d_vol, accumulate);
-    }
-    if (tile_idx.empty()) return adjoint_atomic(ctx, h_poses, n_proj, d_proj, d_vol, accumulate);
+    if (!ok) return adjoint_atomic(ctx, h_poses, n_proj, d_proj, d_vol, accumulate);
     if (!accumulate) TOMO_HIP(ctx, hipMemsetAsync(d_vol, 0, n_vox * sizeof(float), ctx->stream));
-    TOMO_HIP(ctx, hipMemcpyAsync(ctx->d_stage, h, sizeof(AdjC) * (size_t)nt, hipMemcpyHostToDevice, ctx->stream));
-    const dim3 grid((g.nz + 1 + ATZ - 1) / ATZ, (g.ny + 1 + ATY - 1) / ATY, (g.nx + 1 + ATX - 1) / ATX);
-    if (grid.y > 65535 || grid.z > 65535) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "tomo_adjoint: volume too large for the tile grid");
-    rc = tomo_ensure_red(ctx, 8);
+    int rc = tomo_ensure_red(ctx, 8);
     if (rc) return rc;
     unsigned *d_absmax = (unsigned *)(ctx->d_red + 4);
     TOMO_HIP(ctx, hipMemsetAsync(d_absmax, 0, sizeof(unsigned), ctx->stream));
     const int64_t n_y = (int64_t)n_det * n_proj;
     TOMO_LAUNCH(ctx, "k_absmax", k_absmax, dim3((unsigned)std::min<int64_t>((n_y + 255) / 256, 2048)), dim3(256), 0, d_proj, n_y, d_absmax);
-    TOMO_LAUNCH(ctx, "k_adj_tile", k_adj_tile, grid, dim3(ADJ_WAVES * 64), 0, (const AdjC *)ctx->d_stage, nt, d_proj, d_vol, g,
+    TOMO_LAUNCH(ctx, "k_adj_tile", k_tile<false>, grid, dim3(ADJ_WAVES * 64), 0, (const AdjC *)ctx->d_stage, n_proj, (float *)d_proj, d_vol, g,
                 (const unsigned *)d_absmax, (float)weight_bound);
     return TOMO_OK;
 }

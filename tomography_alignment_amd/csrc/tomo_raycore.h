@@ -12,7 +12,7 @@
 // temporaries.  Volumes are read through a zero halo of TOMO_HALO voxels, which turns the
 // per-corner bounds tests into plain loads of zeros (identical result: an out-of-bounds corner
 // contributes 0).  Sample positions inside a block of TOMO_JB samples are float32 offsets from a
-// float64 integer anchor, so coordinates keep ~2e-6 voxel accuracy at 1024^3 where plain float32
+// float64 integer anchor, so coordinates keep ~4e-6 voxel accuracy at 1024^3 where plain float32
 // (ulp 6e-5 at 1024) would not.
 #ifndef TOMO_RAYCORE_H_
 #define TOMO_RAYCORE_H_
@@ -26,7 +26,8 @@
 #endif
 
 #define TOMO_HALO 2   // zero voxels on every side of the padded volume
-#define TOMO_JB 32    // samples per re-anchored block
+#define TOMO_JB 32    // samples per re-anchored block in the ray-driven kernels (in-block offsets < 35: ulp 3.8e-6 voxel)
+#define TOMO_TILE_JB 64  // ... in the tile kernels (rows are short: fewer anchors; offsets < 67: ulp 7.6e-6 voxel)
 
 struct TomoGeomC {    // device-side copy of tomo_geom
     int32_t nx, ny, nz, ndx, ndz;
@@ -155,11 +156,11 @@ TOMO_HD void tomo_ray_range(const double b[3], const double d[3], int n, int nx,
 // Block anchor: one below the integer floor of the smallest coordinate the block [jb, jb+TOMO_JB)
 // reaches, so in-block offsets are >= 1 (their floors stay >= 0 under float32 rounding, which the
 // unsigned 24-bit offset arithmetic of the kernels relies on) and < TOMO_JB*|d|+3.
-TOMO_HD void tomo_block_anchor(const double b[3], const double d[3], int jb, int ia[3], float f0[3])
+TOMO_HD void tomo_block_anchor(const double b[3], const double d[3], int jb, int ia[3], float f0[3], int span = TOMO_JB)
 {
     for (int a = 0; a < 3; ++a) {
         double s = b[a] + (double)jb * d[a];
-        double e = s + (double)(TOMO_JB - 1) * d[a];
+        double e = s + (double)(span - 1) * d[a];
         double f = floor(s < e ? s : e) - 1.0;
         ia[a] = (int)f;
         f0[a] = (float)(s - f);
