@@ -1,0 +1,175 @@
+"""CPU stand-ins used ONLY by the tests: an oracle-backed object with the method set of
+tomography_alignment_amd.backend.HipBackend (so the solvers' control flow can run without a GPU) and a
+torch.distributed (gloo) communicator with the method set of tomography_alignment_amd.comm.RcclComm.
+Nothing in the product imports this module."""
+import numpy as np
+
+from oracle import oracle as orc
+
+
+class Buf(object):
+    """Host 'device buffer': same tiny surface as _lib.DeviceArray."""
+
+    def __init__(self, a):
+        self.a = np.ascontiguousarray(a, np.float32).ravel().copy()
+        self.size = self.a.size
+
+    def download(self):
+        return self.a.copy()
+
+    def upload(self, host):
+        self.a[:] = np.asarray(host, np.float32).ravel()
+        return self
+
+    def copy_from(self, other):
+        self.a[:] = other.a
+        return self
+
+
+class OracleBackend(object):
+    name = "oracle(test)"
+
+    def __init__(self, geometry):
+        self.geometry = geometry
+        self.n_vox = int(np.prod(geometry.vox_shape))
+        self.n_det = int(np.prod(geometry.det_shape))
+        self.og = orc.Geo(geometry.n_proj, np.asarray(geometry.vox_shape), np.ones(3), np.asarray(geometry.det_shape), np.ones(2),
+                          step_size=geometry.step_size)
+        self.calls = {"forward": 0, "adjoint": 0, "cost_grad": 0, "proj_grad": 0}
+
+    def upload(self, host):
+        return Buf(host)
+
+    def download(self, buf):
+        return buf.download()
+
+    def zeros(self, n):
+        return Buf(np.zeros(int(n), np.float32))
+
+    empty = zeros
+
+    def copy(self, dst, src):
+        dst.copy_from(src)
+
+    def is_buffer(self, x):
+        return isinstance(x, Buf)
+
+    def _kw(self, poses):
+        self.og.cor_shift = np.stack([poses[:, 6], np.zeros(len(poses)), np.zeros(len(poses))], axis=1)
+        return dict(phi=poses[:, 0], alpha=poses[:, 1], beta=poses[:, 2], xyz_shift=poses[:, 3:6])
+
+    def forward(self, poses, vol, out):
+        self.calls["forward"] += 1
+        out.a[:] = orc.forward(self.og, vol.a, **self._kw(poses)).astype(np.float32).ravel()
+        return out
+
+    def adjoint(self, poses, proj, out, accumulate=False):
+        self.calls["adjoint"] += 1
+        r = orc.adjoint(self.og, proj.a, **self._kw(poses)).astype(np.float32)
+        out.a[:] = out.a + r if accumulate else r
+        return out
+
+    def proj_grad(self, pose, vol, proj_out, grad_out, row_order=0):
+        self.calls["proj_grad"] += 1
+        p, g = orc.projection_gradient(self.og, vol.a, pose[0, 1], pose[0, 2], pose[0, 0], pose[0, 3:6], np.array([pose[0, 6], 0, 0]))
+        if row_order == 1:
+            g = g[[0, 1, 2, 4, 5, 3]]
+        proj_out.a[:] = p
+        grad_out.a[:] = g.ravel()
+
+    def cost_grad(self, poses, vol, b, resid=None):
+        n = poses.shape[0]
+        cost, g6 = np.zeros(n), np.zeros((n, 6))
+        for i in range(n):
+            self.calls["cost_grad"] += 1
+            p, g = orc.projection_gradient(self.og, vol.a, poses[i, 1], poses[i, 2], poses[i, 0], poses[i, 3:6], np.array([poses[i, 6], 0, 0]))
+            res = b.a.reshape(n, -1)[i].astype(np.float64) - p
+            cost[i] = 0.5 * np.dot(res, res)
+            g6[i] = np.dot(-g.astype(np.float64), res)
+        return cost, g6
+
+    def fill(self, buf, value):
+        buf.a[:] = value
+
+    def recip_guard(self, buf, thresh=None):
+        bad = (buf.a == 0.) if thresh is None else (buf.a < thresh)
+        with np.errstate(divide="ignore"):
+            r = 1. / buf.a
+        r[bad] = 0.
+        buf.a[:] = r
+
+    def residual_scale(self, b, ax, w, out):
+        r = b.a - ax.a
+        out.a[:] = r if w is None else w.a * r
+        return float(np.dot(r.astype(np.float64), r.astype(np.float64)))
+
+    def update(self, rec, bp, v, positivity=False, gt=None):
+        rec.a += bp.a if v is None else bp.a * v.a
+        if positivity:
+            rec.a[rec.a < 0.] = 0.
+        if gt is None:
+            return None
+        e = (gt.a - rec.a).astype(np.float64)
+        return float(np.dot(e, e))
+
+    def axpy(self, y, x, a):
+        y.a += np.float32(a) * x.a
+
+    def xpay(self, y, x, a):
+        y.a[:] = x.a + np.float32(a) * y.a
+
+    def sub(self, out, a, b):
+        out.a[:] = a.a - b.a
+
+    def mul(self, y, x):
+        y.a *= x.a
+
+    def dot(self, a, b):
+        return float(np.dot(a.a.astype(np.float64), b.a.astype(np.float64)))
+
+    def diff_sumsq(self, a, b):
+        e = (a.a - b.a).astype(np.float64)
+        return float(np.dot(e, e))
+
+    def sync(self):
+        pass
+
+
+class GlooComm(object):
+    """torch.distributed (gloo) with the RcclComm method set, on the host buffers above."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank = dist.get_rank()
+        self.size = dist.get_world_size()
+        self.ctx = None
+        self.n_vol_allreduce = 0
+
+    def Get_size(self):
+        return self.size
+
+    def Get_rank(self):
+        return self.rank
+
+    def allreduce_sum_(self, buf):
+        import torch
+        t = torch.from_numpy(buf.a)
+        self.dist.all_reduce(t)
+        self.n_vol_allreduce += 1
+        return buf
+
+    def allreduce_scalar(self, v):
+        import torch
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        self.dist.all_reduce(t)
+        return float(t[0])
+
+    def allreduce_max(self, v):
+        import torch
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def barrier(self):
+        self.dist.barrier()

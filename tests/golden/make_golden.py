@@ -277,6 +277,10 @@ def g6():
                                                         alignment_functions.gradient_xzab,
                                                         args=args + (None,), options={"maxiter": 5})
     out.update(gd_x=xg, gd_f=np.array(fg), gd_stop=np.array(stop))
+    xg1, fg1, stop1 = alignment_functions.gradient_descent(np.zeros(4), alignment_functions.cost_xzab,
+                                                           alignment_functions.gradient_xzab,
+                                                           args=args + (None,), options={"maxiter": 1})
+    out.update(gd1_x=xg1, gd1_f=np.array(fg1), gd1_stop=np.array(stop1))
     save("g6_alignment", **out)
 
 

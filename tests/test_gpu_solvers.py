@@ -1,0 +1,141 @@
+"""GPU tests of the layers above the projectors: device-resident SIRT / CGLS, the alignment API, solver vector
+kernels, the device phantom, event timing, and RCCL bring-up (1 rank) -- all through the C-ABI."""
+import copy
+
+import numpy as np
+import pytest
+from scipy import optimize
+
+from conftest import golden, rel_max
+
+pytestmark = pytest.mark.gpu
+
+
+def geom(n_proj, N, **kw):
+    from tomography_alignment_amd.utilities.geometry import Geometry
+    return Geometry(n_proj, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2), **kw)
+
+
+@pytest.mark.parametrize("tag,positivity,use_gt", [("plain", False, False), ("pos_gt", True, True)])
+def test_sirt_vs_reference_golden(shepp32, tag, positivity, use_gt):
+    from tomography_alignment_amd.recon import sirt
+    g = golden("g5_sirt")
+    geo = geom(16, 32)
+    angles = np.array([g["phi"], g["alpha"], g["beta"]]).T
+    opts = {"ground_truth": shepp32.copy()} if use_gt else {}
+    s = sirt.SIRT(geo, g["b"].copy(), angles, g["xyz"], options=opts)
+    assert rel_max(s.W, g["W"]) < 1e-5 and rel_max(s.V, g["V"]) < 1e-5
+    rec, err = s.run_main_iteration(niter=10, positivity=positivity)
+    assert rec.shape == (32, 32, 32)
+    assert rel_max(rec, g["rec_" + tag]) < 5e-5          # 10 iterations of float32 operators
+    assert np.allclose(err, g["err_" + tag], rtol=5e-5)
+
+
+def test_sharded_sirt_world_of_one_matches_plain(shepp32):
+    from tomography_alignment_amd.recon import sirt_mpi
+    from tomography_alignment_amd.comm import SingleComm
+    g = golden("g5_sirt")
+    geo = geom(16, 32)
+    angles = np.array([g["phi"], g["alpha"], g["beta"]]).T
+    s = sirt_mpi.SIRT(SingleComm(), geo, g["b"].copy(), angles, g["xyz"], options={})
+    rec, err = s.run_main_iteration(niter=10)
+    assert rel_max(rec, g["rec_plain"]) < 5e-5
+
+
+def test_cgls_vs_restated_reference(shepp32):
+    from oracle import oracle as orc
+    from tomography_alignment_amd.recon import cgls
+    g = golden("g5_sirt")
+    geo = geom(16, 32)
+    angles = np.array([g["phi"], g["alpha"], g["beta"]]).T
+    og = orc.Geo(16, np.array([32] * 3), np.ones(3), np.array([32, 32]), np.ones(2))
+    kw = dict(alpha=g["alpha"], beta=g["beta"], phi=g["phi"], xyz_shift=g["xyz"])
+    want, want_err = orc.cgls(lambda x: orc.forward(og, x, **kw).astype(np.float32).ravel(),
+                              lambda y: orc.adjoint(og, y, **kw).astype(np.float32), 32 ** 3, g["b"], 8)
+    rec, err = cgls.CGLS(geo, g["b"].copy(), angles, g["xyz"]).run_main_iteration(niter=8)
+    assert rel_max(rec, want) < 2e-4 and np.allclose(err, want_err, rtol=2e-4)
+
+
+def test_linear_operators_module(shepp32):
+    from tomography_alignment_amd.utilities import linear_operators
+    g = golden("g2_fwd_adj")
+    op = linear_operators.LinearOperator(geom(6, 32))
+    angles = np.array([g["phi"], g["alpha"], g["beta"]]).T
+    assert rel_max(op.project(shepp32, 6, angles, g["xyz"]).ravel(), g["Ax"]) < 1e-5
+    assert rel_max(op.backproject(g["y"], 6, angles, g["xyz"]), g["ATy"]) < 1e-5
+
+
+def test_alignment_api_vs_reference_golden(shepp32):
+    from tomography_alignment_amd.utilities import projection_operators, alignment_functions as af
+    g = golden("g6_alignment")
+    geo = geom(1, 32)
+    this_geo = copy.copy(geo)
+    this_geo.cor_shift = geo.cor_shift[0]
+    P = projection_operators.ProjectionMatrix(geo)
+    ao = af.AlignmentUtilities(g["b"].reshape(32, 32), P, this_geo)
+    args = (ao, shepp32, np.array([float(g["phi0"]), 0., 0.]), np.zeros(3))
+    for tag in ("zero", "gen"):
+        p = g["p_" + tag]
+        assert np.isclose(af.cost_xzab(p, *args), g["cost_xzab_" + tag], rtol=1e-4, atol=1e-8)
+        assert rel_max(af.gradient_xzab(p, *args), g["grad_xzab_" + tag]) < 1e-4
+        p5 = np.array([p[0], p[1], 0.003, p[2], p[3]])
+        assert rel_max(af.gradient_xzpab(p5, *args), g["grad_xzpab_" + tag]) < 1e-4
+    pg = g["p_gen"]
+    assert rel_max(af.gradient_xzab(pg, *args, return_vector=True), g["grad_xzab_vec"]) < 1e-5
+    assert rel_max(af.cost_xzab(pg, *args, return_vector=True), g["cost_xzab_vec"]) < 1e-5
+    res = optimize.minimize(af.cost_xzab, np.zeros(4), method="L-BFGS-B", jac=af.gradient_xzab, args=args,
+                            bounds=((-3., 3.), (-3., 3.), (-0.02, 0.02), (-0.02, 0.02)), options={"disp": False})
+    assert np.allclose(res.x, g["true"], atol=5e-5)        # the injected (tx, tz, alpha, beta) is recovered
+    assert res.fun < 1e-6
+
+
+def test_vector_kernels_phantom_timer_profile():
+    from tomography_alignment_amd.backend import HipBackend
+    from tomography_alignment_amd.utilities.generate_phantom import SHEPP_LOGAN, shepp3d
+    geo = geom(2, 32)
+    be = HipBackend(geo)
+    rng = np.random.default_rng(0)
+    n = 100003
+    a, b = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    da, db, dc = be.upload(a), be.upload(b), be.empty(n)
+    assert np.isclose(be.dot(da, db), np.dot(a.astype(np.float64), b.astype(np.float64)), rtol=1e-10)
+    assert np.isclose(be.diff_sumsq(da, db), np.sum((a.astype(np.float64) - b) ** 2), rtol=1e-6)
+    be.sub(dc, da, db)
+    assert np.array_equal(dc.download(), a - b)
+    be.axpy(dc, da, 0.5)
+    assert np.allclose(dc.download(), (a - b) + np.float32(0.5) * a, rtol=1e-6, atol=1e-6)
+    be.xpay(dc, db, 2.0)
+    w = a.copy()
+    w[::7] = 0.0
+    dw = be.upload(w)
+    be.recip_guard(dw)
+    got = dw.download()
+    assert np.all(got[::7] == 0.0) and np.allclose(got[1::7], 1.0 / w[1::7], rtol=1e-6)
+    dw = be.upload(np.abs(w) * 1e-7)
+    be.recip_guard(dw, 1e-8)
+    assert np.all(dw.download()[np.abs(w) * 1e-7 < 1e-8] == 0.0)
+    s = be.residual_scale(da, db, None, dc)
+    assert np.isclose(s, np.sum((a.astype(np.float64) - b) ** 2), rtol=1e-6) and np.array_equal(dc.download(), a - b)
+    vol = be.phantom(be.empty(32 ** 3), (32, 32, 32), SHEPP_LOGAN).download().reshape(32, 32, 32)
+    assert np.mean(vol != shepp3d(32)) < 1e-3 and rel_max(vol, golden("g7_phantom")["shepp32"]) <= 1.0
+    be.ctx.profile_reset()
+    be.ctx.profile_enable(True)
+    be.ctx.timer_start()
+    be.dot(da, db)
+    ms = be.ctx.timer_stop()
+    be.ctx.profile_enable(False)
+    n_launch, tot = be.ctx.profile_get("k_dot")
+    assert n_launch == 1 and 0.0 < tot <= ms + 1.0
+
+
+def test_rccl_single_rank_allreduce():
+    from tomography_alignment_amd import _lib
+    from tomography_alignment_amd.comm import RcclComm
+    ctx = _lib.Context(0)
+    comm = RcclComm(ctx, 0, 1, RcclComm.unique_id(ctx.lib))
+    x = ctx.to_device(np.arange(1000, dtype=np.float32))
+    comm.allreduce_sum_(x)
+    ctx.sync()
+    assert np.array_equal(x.download(), np.arange(1000, dtype=np.float32))
+    assert comm.allreduce_scalar(2.5) == 2.5 and comm.allreduce_max(-1.0) == -1.0
+    comm.close()
