@@ -24,7 +24,10 @@ def test_sirt_vs_reference_golden(shepp32, tag, positivity, use_gt):
     angles = np.array([g["phi"], g["alpha"], g["beta"]]).T
     opts = {"ground_truth": shepp32.copy()} if use_gt else {}
     s = sirt.SIRT(geo, g["b"].copy(), angles, g["xyz"], options=opts)
-    assert rel_max(s.W, g["W"]) < 1e-5 and rel_max(s.V, g["V"]) < 1e-5
+    # W = 1/(A.1) blows up for rays that graze a corner (row sum ~1e-3): compare the row / column sums themselves
+    inv = lambda v: np.divide(1.0, v, out=np.zeros_like(v), where=v != 0)    # noqa: E731
+    assert np.array_equal(s.W == 0, g["W"] == 0) and rel_max(inv(s.W), inv(g["W"])) < 1e-5
+    assert np.array_equal(s.V == 0, g["V"] == 0) and rel_max(inv(s.V), inv(g["V"])) < 1e-5
     rec, err = s.run_main_iteration(niter=10, positivity=positivity)
     assert rec.shape == (32, 32, 32)
     assert rel_max(rec, g["rec_" + tag]) < 5e-5          # 10 iterations of float32 operators

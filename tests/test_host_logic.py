@@ -210,3 +210,20 @@ def test_lbfgs_pose_recovery_and_gradient_descent_vs_reference_golden(shepp32):
     x5, f5, stop5 = gd(np.zeros(4), alignment_functions.cost_xzab, alignment_functions.gradient_xzab, args=args + (None,),
                        options={"maxiter": 5})
     assert stop5 == int(g["gd_stop"]) and f5 < f1 and np.isclose(f5, g["gd_f"], rtol=0.2)
+
+
+def test_reference_style_top_level_imports():
+    """INTEGRATION.md level 1: with the package directory itself on sys.path, the reference's own import lines
+    (`from utilities import ...`, `from recon import sirt`, examples/align_rigid.py:5-7) resolve to this package."""
+    import subprocess
+    import sys
+    code = ("from utilities import geometry, projection_operators, alignment_functions, linear_operators, generate_phantom, rotations\n"
+            "from recon import sirt, cgls, sirt_mpi, cgls_mpi\n"
+            "from utilities.alignment_functions import cost_xzab, gradient_xzab\n"
+            "import numpy as np\n"
+            "g = geometry.Geometry(2, np.array([8, 8, 8]), np.ones(3), np.array([8, 8]), np.ones(2))\n"
+            "assert projection_operators.ProjectionMatrix(g).precision is np.float32 and sirt.SIRT and cgls.CGLS\n"
+            "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "tomography_alignment_amd"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd="/tmp", capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr

@@ -10,7 +10,10 @@ import ctypes
 
 import numpy as np
 
-from . import _lib
+try:
+    from . import _lib
+except ImportError:      # package directory itself on sys.path (reference-style `import utilities` layout)
+    import _lib
 
 _c_vp = ctypes.c_void_p
 

@@ -15,7 +15,10 @@ import time
 
 import numpy as np
 
-from . import _lib
+try:
+    from . import _lib
+except ImportError:      # package directory itself on sys.path
+    import _lib
 
 
 class SingleComm(object):

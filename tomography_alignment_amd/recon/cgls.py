@@ -8,7 +8,10 @@ current `rec`; two consecutive restarts quit (:60-68).
 """
 import numpy as np
 
-from ..utilities import projection_operators
+try:
+    from ..utilities import projection_operators
+except ImportError:      # imported as top-level `recon`
+    from utilities import projection_operators
 
 
 class CGLS(object):

@@ -22,7 +22,10 @@ class CGLS(_CGLS):
         self.my_n_proj = np.size(self.my_index)
         opts = dict(options)
         if '_backend' not in opts and getattr(comm, "ctx", None) is not None:
-            from ..backend import HipBackend
+            try:
+                from ..backend import HipBackend
+            except ImportError:
+                from backend import HipBackend
             opts['_backend'] = HipBackend(_SIRT_shard(geometry, self.my_index), ctx=comm.ctx)
         super(CGLS, self).__init__(geometry, projections, angles, xyz_shifts, opts)
 

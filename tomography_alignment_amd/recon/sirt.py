@@ -15,8 +15,10 @@ import time
 
 import numpy as np
 
-from .. import _lib
-from ..utilities import projection_operators
+try:
+    from ..utilities import projection_operators
+except ImportError:      # imported as top-level `recon` (package directory on sys.path, like the reference tree)
+    from utilities import projection_operators
 
 
 class SIRT(object):

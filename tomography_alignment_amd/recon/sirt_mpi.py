@@ -28,7 +28,10 @@ class SIRT(_SIRT):
         self.my_n_proj = np.size(self.my_index)
         opts = dict(options)
         if '_backend' not in opts and getattr(comm, "ctx", None) is not None:
-            from ..backend import HipBackend
+            try:
+                from ..backend import HipBackend
+            except ImportError:
+                from backend import HipBackend
             opts['_backend'] = HipBackend(self._shard_geometry(geometry, self.my_index), ctx=comm.ctx)
         super(SIRT, self).__init__(geometry, projections, angles, xyz_shifts, opts)
 

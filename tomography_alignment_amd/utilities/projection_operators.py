@@ -15,8 +15,12 @@ utilities/projection_operators.py:112-122, rows tx, ty, tz, phi, alpha, beta.
 """
 import numpy as np
 
-from .. import _lib
-from ..backend import HipBackend
+try:
+    from .. import _lib
+    from ..backend import HipBackend
+except ImportError:      # imported as top-level `utilities` (package directory on sys.path, like the reference tree)
+    import _lib
+    from backend import HipBackend
 
 
 def _normalise_poses(geometry, alpha, beta, phi, xyz_shift):
