@@ -136,6 +136,16 @@ TOMO_API int tomo_cost_grad(tomo_ctx *ctx, const double *h_poses, int n, const f
 TOMO_API int tomo_triplets(tomo_ctx *ctx, const double *h_pose, int64_t capacity, int32_t *h_dat, int32_t *h_det,
                   double *h_wts, int64_t *n_inds);
 
+/* tomo_vox_splat / tomo_vox_triplets: the voxel-driven bilinear splat of src/vox_wt_grad.f90 as driven by
+ *   utilities/voxel_utilities.py:51-108 (forward_sparse, forward_proj_grad): x' = Ry(beta)(Rx(alpha) Rz(phi) c + t),
+ *   u = x'_x - (origin_x - cor_x), v = x'_z - (origin_z - cor_z); 4 bilinear weights per voxel with per-pixel bounds
+ *   tests (src/vox_wt_grad.f90:25-49,80-106).  Detector index is x-fastest: fx + ndx*fz (:83) -- unlike the ray path.
+ *   tomo_vox_splat: d_img [ndz*ndx] (index z*ndx+x) = bilinear_vox_interp's det_img.ravel(); d_grad (nullable)
+ *   [6][ndz*ndx], rows tx,ty,tz,phi,alpha,beta (utilities/voxel_utilities.py:23-48 derivative_rigid), float32.
+ *   tomo_vox_triplets: 4 slots per voxel in emission order; h_det[slot] = -1 for an out-of-bounds corner. */
+TOMO_API int tomo_vox_splat(tomo_ctx *ctx, const double *h_pose, const double *h_cor3, const float *d_vol, float *d_img, float *d_grad);
+TOMO_API int tomo_vox_triplets(tomo_ctx *ctx, const double *h_pose, const double *h_cor3, int32_t *h_det4, float *h_wts4);
+
 /* tomo_phantom_ellipsoids: synthetic test volume (sum of ellipsoid indicator values, clipped at 0) with the
  *   parametrisation of utilities/generate_phantom.py:81-179,194-209: table rows
  *   (A, a, b, c, x0, y0, z0, phi, theta, psi), coordinates linspace(-1,1,n) per axis.  bench/test input only. */

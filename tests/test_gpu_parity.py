@@ -231,3 +231,65 @@ def test_properties_at_256(PM):
     A0 = P.projection_matrix(phi=np.array([0.0]))
     ones = A0.dot(np.ones(N ** 3, np.float32)).reshape(N, N)
     assert np.allclose(ones[8:-8, 8:-8], N, rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_csr_materialisation_vs_reference_golden(PM, case):
+    """G1: tocsr() against the reference's own projection_matrix CSR (assembled operator, not triplet order)."""
+    from scipy import sparse
+    g = golden("g1_operator")
+    ref = sparse.csr_matrix((g[case + "_data"], g[case + "_indices"], g[case + "_indptr"]), shape=tuple(g[case + "_shape"]))
+    if case == "a":
+        A = PM(geo_pair(3, 8)[0]).projection_matrix()
+    elif case == "b":
+        A = PM(geo_pair(3, 8, cor_shift=g["b_cor"])[0]).projection_matrix(alpha=g["b_alpha"], beta=g["b_beta"], phi=g["b_phi"], xyz_shift=g["b_xyz"])
+    elif case == "c":
+        A = PM(geo_pair(2, 16, step=0.5, ndet=[12, 12])[0], precision=np.float64).projection_matrix(
+            alpha=g["c_alpha"], beta=g["c_beta"], phi=g["c_phi"], xyz_shift=g["c_xyz"], voxel_mask=g["c_mask"])
+    else:
+        A = PM(geo_pair(1, 8)[0]).projection_matrix(phi=np.array([0.4]), alpha=np.array([0.01]), beta=np.array([-0.02]),
+                                                    xyz_shift=np.array([[0.5, 0.0, -0.25]]))
+    M = A.tocsr()
+    assert sparse.isspmatrix_csr(M) and M.shape == ref.shape and M.dtype == ref.dtype
+    M.sum_duplicates(); M.sort_indices()
+    D = (M - ref).tocoo()
+    assert (np.max(np.abs(D.data)) if D.nnz else 0.0) < (1e-12 if case == "c" else 1e-6)
+    assert abs(M.nnz - ref.nnz) <= 0.002 * ref.nnz + 8      # integer coordinates: a ~1e-16 weight may sit on either neighbour
+    x = np.random.default_rng(0).standard_normal(M.shape[1])
+    assert rel_max(A.dot(x), M.dot(x)) < TOL                # the matrix-free kernels are this matrix
+
+
+def test_triplet_emission_order_vs_oracle(PM, orc):
+    from tomography_alignment_amd import _lib
+    geo, og = geo_pair(1, 12)
+    P = PM(geo)
+    pose = _lib.poses_array([0.7], [0.02], [-0.015], np.array([[0.6, 0.3, -1.2]]), np.array([0.4, 0., 0.]))
+    dat, det, wts = P.backend.triplets(pose)
+    d0, r0, w0 = orc.forward_sparse(og, 0.02, -0.015, 0.7, np.array([0.6, 0.3, -1.2]), np.array([0.4, 0., 0.]))
+    assert np.array_equal(dat, d0) and np.array_equal(det, r0) and np.allclose(wts, w0, rtol=0, atol=1e-12)
+
+
+def test_voxel_splat_vs_reference_golden(PM):
+    """G8: utilities/voxel_utilities.forward_sparse / forward_proj_grad of the reference (src/vox_wt_grad.f90)."""
+    from scipy import sparse
+    from tomography_alignment_amd.utilities import voxel_utilities
+    g = golden("g8_voxel_splat")
+    x = golden("g7_phantom")["shepp16"]
+    for i in range(2):
+        geo, _ = geo_pair(1, 16)
+        geo.cor_shift = g["cor"][i]
+        d, r, w = voxel_utilities.forward_sparse(geo, g["alpha"][i], g["beta"][i], g["phi"][i], g["xyz"][i])
+        assert w.dtype == np.float32
+        A = sparse.csr_matrix(sparse.coo_matrix((w, (r, d)), shape=(256, 4096)))
+        ref = sparse.csr_matrix((g["s%d_data" % i], g["s%d_indices" % i], g["s%d_indptr" % i]), shape=tuple(g["s%d_shape" % i]))
+        A.sum_duplicates(); A.sort_indices()
+        D = (A - ref).tocoo()
+        assert (np.max(np.abs(D.data)) if D.nnz else 0.0) < 2e-6 and abs(A.nnz - ref.nnz) <= 0.002 * ref.nnz + 4
+        img, grad = voxel_utilities.forward_proj_grad(geo, g["alpha"][i], g["beta"][i], g["phi"][i], g["xyz"][i], x)
+        assert grad.shape == (6, 256)
+        assert rel_max(img, g["img%d" % i]) < TOL
+        assert rel_max(grad, g["grad%d" % i]) < 3e-5      # float32 sums of ~16 terms in atomic order vs the Fortran's serial order
+    P = PM(geo_pair(2, 16)[0])
+    P.projection_matrix(alpha=g["alpha"], beta=g["beta"], phi=g["phi"], xyz_shift=g["xyz"])
+    wts, dets, dats = P._forward_voxel()
+    assert len(wts) == 2 and dets[1].min() >= 256

@@ -54,6 +54,8 @@ SIGNATURES = {
     "tomo_proj_grad": (ctypes.c_int, [_c_vp, _c_dp, _c_vp, _c_vp, _c_vp, ctypes.c_int]),
     "tomo_cost_grad": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp, _c_dp, _c_dp, _c_vp]),
     "tomo_triplets": (ctypes.c_int, [_c_vp, _c_dp, _c_i64, _c_vp, _c_vp, _c_vp, ctypes.POINTER(_c_i64)]),
+    "tomo_vox_splat": (ctypes.c_int, [_c_vp, _c_dp, _c_dp, _c_vp, _c_vp, _c_vp]),
+    "tomo_vox_triplets": (ctypes.c_int, [_c_vp, _c_dp, _c_dp, _c_vp, _c_vp]),
     "tomo_phantom_ellipsoids": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp, ctypes.c_int]),
     "tomo_vec_recip_guard": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, ctypes.c_float, ctypes.c_int]),
     "tomo_vec_fill": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, ctypes.c_float]),

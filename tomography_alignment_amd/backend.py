@@ -91,6 +91,36 @@ class HipBackend(object):
                                                resid.ptr if resid is not None else None))
         return cost, g6
 
+    def triplets(self, pose):
+        """COO triplets (dat_inds, det_inds, wts float64) of one projection in the emission order of
+        src/ray_wt_grad.f90:1-92 (small volumes only)."""
+        self._geom()
+        n = ctypes.c_int64(0)
+        self.ctx.check(self.lib.tomo_triplets(self.ctx.handle, _lib.dptr(pose), 0, None, None, None, ctypes.byref(n)))
+        dat, det, wts = np.empty(n.value, np.int32), np.empty(n.value, np.int32), np.empty(n.value, np.float64)
+        if n.value:
+            self.ctx.check(self.lib.tomo_triplets(self.ctx.handle, _lib.dptr(pose), n.value, dat.ctypes.data_as(_c_vp),
+                                                  det.ctypes.data_as(_c_vp), wts.ctypes.data_as(_c_vp), ctypes.byref(n)))
+        return dat, det, wts
+
+    def vox_splat(self, pose, cor3, vol, img_out, grad_out=None):
+        self._geom()
+        cor3 = np.ascontiguousarray(cor3, np.float64).reshape(3)
+        self.ctx.check(self.lib.tomo_vox_splat(self.ctx.handle, _lib.dptr(pose), _lib.dptr(cor3), vol.ptr, img_out.ptr,
+                                               grad_out.ptr if grad_out is not None else None))
+
+    def vox_triplets(self, pose, cor3):
+        """(dat_inds, det_inds, wts float32) of src/vox_wt_grad.f90:58-112 bilinear_sparse, in its emission order."""
+        self._geom()
+        cor3 = np.ascontiguousarray(cor3, np.float64).reshape(3)
+        det4 = np.empty(4 * self.n_vox, np.int32)
+        w4 = np.empty(4 * self.n_vox, np.float32)
+        self.ctx.check(self.lib.tomo_vox_triplets(self.ctx.handle, _lib.dptr(pose), _lib.dptr(cor3), det4.ctypes.data_as(_c_vp),
+                                                  w4.ctypes.data_as(_c_vp)))
+        keep = det4 >= 0
+        dat = (np.arange(4 * self.n_vox, dtype=np.int64) // 4).astype(np.int32)
+        return dat[keep], det4[keep], w4[keep]
+
     def phantom(self, out, shape, table):
         """Fill `out` with the ellipsoid phantom of utilities/generate_phantom (generated on the device)."""
         table = np.ascontiguousarray(table, np.float64)

@@ -842,7 +842,243 @@ extern "C" int tomo_cost_grad(tomo_ctx *ctx, const double *h_poses, int n, const
     return TOMO_OK;
 }
 
-extern "C" int tomo_triplets(tomo_ctx *ctx, const double *, int64_t, int32_t *, int32_t *, double *, int64_t *)
+// ------------------------------------------------------------------------------------------------
+// COO triplets of one projection (src/ray_wt_grad.f90:1-92 trilinear_ray_sparse): count -> scan -> fill, float64
+// weights, emission order ray-major / sample / corner (x slowest, z fastest, floor before ceil).  Small volumes only
+// (8 slots per sample): this is the "materialise a real scipy CSR" path, not a hot path.
+// ------------------------------------------------------------------------------------------------
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_triplets(const ProjC *__restrict__ pcs, TomoGeomC g, const int64_t *__restrict__ offsets,
+                                                  int32_t *__restrict__ counts, int32_t *__restrict__ dat, int32_t *__restrict__ det,
+                                                  double *__restrict__ wts)
 {
-    return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "tomo_triplets: not built yet");
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_det = g.ndx * g.ndz;
+    if (r >= n_det) return;
+    const int ix = r / g.ndz, iz = r - ix * g.ndz;
+    const ProjC &c = pcs[0];
+    double b[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) b[a] = c.p0[a] + (double)ix * c.u[a] + (double)iz * c.w[a];
+    int j0, j1;
+    tomo_ray_range(b, c.d, c.n, g.nx, g.ny, g.nz, j0, j1);
+    int64_t o = FILL ? offsets[r] : 0;
+    int cnt = 0;
+    for (int j = j0; j < j1; ++j) {
+        double p[3], f[3], wf[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            p[a] = b[a] + (double)j * c.d[a];                 // utilities/ray_voxel_utilities.py:93
+            f[a] = floor(p[a]);                               // :96
+            wf[a] = 1.0 - (p[a] - f[a]);                      // :98-99
+        }
+        const int fx = (int)f[0], fy = (int)f[1], fz = (int)f[2];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int x = fx + (k >> 2), y = fy + ((k >> 1) & 1), z = fz + (k & 1);
+            if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {      // src/ray_wt_grad.f90:35-89
+                if (FILL) {
+                    const double wx = (k >> 2) ? 1.0 - wf[0] : wf[0], wy = ((k >> 1) & 1) ? 1.0 - wf[1] : wf[1], wz = (k & 1) ? 1.0 - wf[2] : wf[2];
+                    det[o] = r;
+                    dat[o] = (x * g.ny + y) * g.nz + z;
+                    wts[o] = wx * wy * wz;
+                    ++o;
+                }
+                ++cnt;
+            }
+        }
+    }
+    if (!FILL) counts[r] = cnt;
+}
+
+extern "C" int tomo_triplets(tomo_ctx *ctx, const double *h_pose, int64_t capacity, int32_t *h_dat, int32_t *h_det, double *h_wts,
+                             int64_t *n_inds)
+{
+    TOMO_NEED_GEOM(ctx);
+    if (!h_pose || !n_inds) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_triplets: bad args");
+    const TomoGeomC &g = ctx->g;
+    const int n_det = g.ndx * g.ndz;
+    if ((size_t)g.nx * g.ny * g.nz >= ((size_t)1 << 31)) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "tomo_triplets: int32 voxel indices");
+    ProjC *d_pc = nullptr;
+    int rc = upload_projc(ctx, h_pose, 1, false, &d_pc, nullptr);
+    if (rc) return rc;
+    int32_t *d_counts = nullptr;
+    int64_t *d_off = nullptr;
+    TOMO_HIP(ctx, hipMalloc((void **)&d_counts, sizeof(int32_t) * (size_t)n_det));
+    TOMO_HIP(ctx, hipMalloc((void **)&d_off, sizeof(int64_t) * (size_t)n_det));
+    const dim3 grid((n_det + 255) / 256);
+    std::vector<int32_t> counts(n_det);
+    std::vector<int64_t> off(n_det);
+    int result = TOMO_OK;
+    int32_t *d_dat = nullptr, *d_det = nullptr;
+    double *d_w = nullptr;
+    do {
+        hipLaunchKernelGGL(k_triplets<false>, grid, dim3(256), 0, ctx->stream, (const ProjC *)d_pc, g, (const int64_t *)nullptr, d_counts,
+                           (int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr);
+        if (hipMemcpyAsync(counts.data(), d_counts, sizeof(int32_t) * (size_t)n_det, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { result = tomo_fail(ctx, TOMO_ERR_HIP, "tomo_triplets: count pass failed"); break; }
+        int64_t total = 0;
+        for (int r = 0; r < n_det; ++r) { off[r] = total; total += counts[r]; }
+        *n_inds = total;
+        if (!h_dat || !h_det || !h_wts) break;                  // count query
+        if (capacity < total) { result = tomo_fail(ctx, TOMO_ERR_ARG, "tomo_triplets: capacity too small"); break; }
+        if (total == 0) break;
+        if (hipMalloc((void **)&d_dat, sizeof(int32_t) * (size_t)total) != hipSuccess || hipMalloc((void **)&d_det, sizeof(int32_t) * (size_t)total) != hipSuccess ||
+            hipMalloc((void **)&d_w, sizeof(double) * (size_t)total) != hipSuccess) { result = tomo_fail(ctx, TOMO_ERR_HIP, "tomo_triplets: out of device memory"); break; }
+        (void)hipMemcpyAsync(d_off, off.data(), sizeof(int64_t) * (size_t)n_det, hipMemcpyHostToDevice, ctx->stream);
+        hipLaunchKernelGGL(k_triplets<true>, grid, dim3(256), 0, ctx->stream, (const ProjC *)d_pc, g, (const int64_t *)d_off, (int32_t *)nullptr, d_dat,
+                           d_det, d_w);
+        (void)hipMemcpyAsync(h_dat, d_dat, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipMemcpyAsync(h_det, d_det, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipMemcpyAsync(h_wts, d_w, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) result = tomo_fail(ctx, TOMO_ERR_HIP, "tomo_triplets: fill pass failed");
+    } while (0);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (d_dat) (void)hipFree(d_dat);
+    if (d_det) (void)hipFree(d_det);
+    if (d_w) (void)hipFree(d_w);
+    (void)hipFree(d_counts);
+    (void)hipFree(d_off);
+    return result;
+}
+
+// ------------------------------------------------------------------------------------------------
+// voxel-driven bilinear splat (src/vox_wt_grad.f90, utilities/voxel_utilities.py): one voxel per work-item, lanes
+// along z; 4 (+24 with the Jacobian) global float atomics per voxel.  Dead code in the reference
+// (utilities/projection_operators.py:54 hard-wires the ray path), built for completeness of SURVEY 8a row A9.
+// ------------------------------------------------------------------------------------------------
+struct VoxC {
+    double m[3][3];     // Ry Rx Rz
+    double off[3];      // Ry t
+    double org[3];      // vox_origin - cor_shift
+    float rb[3][3];     // Ry           (der rows 0-2 are its columns)
+    double a3[3][3];    // Ry Rx dRz    (der row 3 = a3 c)
+    double a4[3][3];    // Ry dRx Rz    (der row 4 = a4 c)
+    double drb[3][3];   // dRy          (der row 5 = dRy (Rx Rz c + t))
+    double rxz[3][3];   // Rx Rz
+    double t[3];
+};
+
+template <int MODE>   // 0 splat value, 1 splat value + gradient, 2 triplets
+__global__ __launch_bounds__(256) void k_vox_splat(VoxC c, TomoGeomC g, double px, double py, double pz, const float *__restrict__ vol,
+                                                   float *__restrict__ img, float *__restrict__ grad, int32_t *__restrict__ det4,
+                                                   float *__restrict__ wts4)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int iz = blockIdx.x * 64 + lane, iy = blockIdx.y * 4 + wv, ix = blockIdx.z;
+    if (iy >= g.ny || iz >= g.nz) return;
+    const size_t i = ((size_t)ix * g.ny + iy) * g.nz + iz;
+    const double cx = g.org[0] + ix * px, cy = g.org[1] + iy * py, cz = g.org[2] + iz * pz;      // geometry.py:82-86
+    const double rx = c.m[0][0] * cx + c.m[0][1] * cy + c.m[0][2] * cz + c.off[0];
+    const double rz = c.m[2][0] * cx + c.m[2][1] * cy + c.m[2][2] * cz + c.off[2];
+    const double u = rx - c.org[0], v = rz - c.org[2];
+    const double fu = floor(u), fv = floor(v);                                                   // voxel_utilities.py:64-65
+    const float ax = (float)(u - fu), az = (float)(v - fv);                                      // :66-67
+    const bool sane = fabs(fu) < 2e9 && fabs(fv) < 2e9;
+    const int fx = sane ? (int)fu : -10, fz = sane ? (int)fv : -10;
+    const int ndx = g.ndx, ndz = g.ndz;
+    const size_t n_pix = (size_t)ndx * ndz;
+    float rec = 0.f, der0[6], der2[6];
+    if (MODE != 2) rec = vol[i];
+    if (MODE == 1) {
+        // der rows (voxel_utilities.py:38-46), only columns 0 and 2 (x', z') are used by the splat
+        double q[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) q[a] = c.rxz[a][0] * cx + c.rxz[a][1] * cy + c.rxz[a][2] * cz + c.t[a];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { der0[k] = c.rb[0][k]; der2[k] = c.rb[2][k]; }
+        der0[3] = (float)(c.a3[0][0] * cx + c.a3[0][1] * cy + c.a3[0][2] * cz);
+        der2[3] = (float)(c.a3[2][0] * cx + c.a3[2][1] * cy + c.a3[2][2] * cz);
+        der0[4] = (float)(c.a4[0][0] * cx + c.a4[0][1] * cy + c.a4[0][2] * cz);
+        der2[4] = (float)(c.a4[2][0] * cx + c.a4[2][1] * cy + c.a4[2][2] * cz);
+        der0[5] = (float)(c.drb[0][0] * q[0] + c.drb[0][1] * q[1] + c.drb[0][2] * q[2]);
+        der2[5] = (float)(c.drb[2][0] * q[0] + c.drb[2][1] * q[1] + c.drb[2][2] * q[2]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {          // emission order (fx,fz),(fx+1,fz),(fx,fz+1),(fx+1,fz+1): src/vox_wt_grad.f90:80-106
+        const int a = k & 1, b = k >> 1;
+        const int x = fx + a, z = fz + b;
+        const bool ok = x >= 0 && x < ndx && z >= 0 && z < ndz;
+        const float wx = a ? ax : 1.f - ax, wz = b ? az : 1.f - az;
+        if (MODE == 2) {
+            det4[4 * i + k] = ok ? x + ndx * z : -1;
+            wts4[4 * i + k] = wx * wz;
+        } else if (ok) {
+            const size_t o = (size_t)z * ndx + x;
+            atomicAdd(&img[o], rec * wx * wz);
+            if (MODE == 1) {
+                // src/vox_wt_grad.f90:27-28,33-34,39-40,45-46 (signs as written there)
+                const float f0 = (a ? -1.f : 1.f) * (b ? az : 1.f - az);
+                const float f2 = (b ? -1.f : 1.f) * (a ? ax : 1.f - ax);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) atomicAdd(&grad[(size_t)r * n_pix + o], der0[r] * f0 * rec + der2[r] * f2 * rec);
+            }
+        }
+    }
+}
+
+static void make_voxc(const tomo_ctx *ctx, const double *pose, const double *cor3, VoxC &c)
+{
+    const TomoGeomC &g = ctx->g;
+    TomoM3 Rz = tomo_rz(pose[0]), Rx = tomo_rx(pose[1]), Ry = tomo_ry(pose[2]);
+    TomoM3 dRz = tomo_drz(pose[0]), dRx = tomo_drx(pose[1]), dRy = tomo_dry(pose[2]);
+    TomoM3 Rxz = tomo_mm(Rx, Rz), M = tomo_mm(Ry, Rxz);
+    TomoM3 A3 = tomo_mm(tomo_mm(Ry, Rx), dRz), A4 = tomo_mm(Ry, tomo_mm(dRx, Rz));
+    const double t[3] = {pose[3], pose[4], pose[5]};
+    tomo_mv(Ry, t, c.off);
+    for (int i = 0; i < 3; ++i) {
+        c.org[i] = g.org[i] - (cor3 ? cor3[i] : 0.0);
+        c.t[i] = t[i];
+        for (int j = 0; j < 3; ++j) {
+            c.m[i][j] = M.m[i][j]; c.rb[i][j] = (float)Ry.m[i][j]; c.a3[i][j] = A3.m[i][j]; c.a4[i][j] = A4.m[i][j];
+            c.drb[i][j] = dRy.m[i][j]; c.rxz[i][j] = Rxz.m[i][j];
+        }
+    }
+}
+
+extern "C" int tomo_vox_splat(tomo_ctx *ctx, const double *h_pose, const double *h_cor3, const float *d_vol, float *d_img, float *d_grad)
+{
+    TOMO_NEED_GEOM(ctx);
+    if (!h_pose || !d_vol || !d_img) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_vox_splat: bad args");
+    const TomoGeomC &g = ctx->g;
+    if (g.nx > TOMO_MAX_GRID_Z) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "tomo_vox_splat: nx > 65535");
+    VoxC c;
+    make_voxc(ctx, h_pose, h_cor3, c);
+    const size_t n_pix = (size_t)g.ndx * g.ndz;
+    TOMO_HIP(ctx, hipMemsetAsync(d_img, 0, n_pix * sizeof(float), ctx->stream));
+    const dim3 grid((g.nz + 63) / 64, (g.ny + 3) / 4, g.nx);
+    if (d_grad) {
+        TOMO_HIP(ctx, hipMemsetAsync(d_grad, 0, 6 * n_pix * sizeof(float), ctx->stream));
+        TOMO_LAUNCH(ctx, "k_vox_splat", k_vox_splat<1>, grid, dim3(256), 0, c, g, ctx->vox_pitch[0], ctx->vox_pitch[1], ctx->vox_pitch[2], d_vol, d_img,
+                    d_grad, (int32_t *)nullptr, (float *)nullptr);
+    } else {
+        TOMO_LAUNCH(ctx, "k_vox_splat", k_vox_splat<0>, grid, dim3(256), 0, c, g, ctx->vox_pitch[0], ctx->vox_pitch[1], ctx->vox_pitch[2], d_vol, d_img,
+                    (float *)nullptr, (int32_t *)nullptr, (float *)nullptr);
+    }
+    return TOMO_OK;
+}
+
+extern "C" int tomo_vox_triplets(tomo_ctx *ctx, const double *h_pose, const double *h_cor3, int32_t *h_det4, float *h_wts4)
+{
+    TOMO_NEED_GEOM(ctx);
+    if (!h_pose || !h_det4 || !h_wts4) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_vox_triplets: bad args");
+    const TomoGeomC &g = ctx->g;
+    if (g.nx > TOMO_MAX_GRID_Z) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "tomo_vox_triplets: nx > 65535");
+    const size_t n4 = 4 * (size_t)g.nx * g.ny * g.nz;
+    VoxC c;
+    make_voxc(ctx, h_pose, h_cor3, c);
+    int32_t *d_det = nullptr;
+    float *d_w = nullptr;
+    TOMO_HIP(ctx, hipMalloc((void **)&d_det, n4 * sizeof(int32_t)));
+    if (hipMalloc((void **)&d_w, n4 * sizeof(float)) != hipSuccess) { (void)hipFree(d_det); return tomo_fail(ctx, TOMO_ERR_HIP, "tomo_vox_triplets: out of device memory"); }
+    const dim3 grid((g.nz + 63) / 64, (g.ny + 3) / 4, g.nx);
+    hipLaunchKernelGGL(k_vox_splat<2>, grid, dim3(256), 0, ctx->stream, c, g, ctx->vox_pitch[0], ctx->vox_pitch[1], ctx->vox_pitch[2], (const float *)nullptr,
+                       (float *)nullptr, (float *)nullptr, d_det, d_w);
+    hipError_t e = hipMemcpyAsync(h_det4, d_det, n4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_wts4, d_w, n4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_det);
+    (void)hipFree(d_w);
+    if (e != hipSuccess) return tomo_fail(ctx, TOMO_ERR_HIP, std::string("tomo_vox_triplets: ") + hipGetErrorString(e));
+    return TOMO_OK;
 }

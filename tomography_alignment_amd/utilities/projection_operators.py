@@ -143,9 +143,33 @@ class RayOperator(object):
         res = out.download()
         return res if self.dtype == np.float32 else res.astype(self.dtype)
 
-    def tocsr(self):
-        raise NotImplementedError("matrix-free operator: CSR materialisation is only offered for small volumes "
-                                  "via ProjectionMatrix.assemble_csr()")
+    def tocsr(self, max_nnz=2 ** 31 - 1):
+        """Materialise the scipy CSR the reference's projection_matrix returns (utilities/projection_operators.py:56-76):
+        per-projection COO triplets (emitted on the device with the order and float64 weights of
+        src/ray_wt_grad.f90:1-92), weights cast to `precision`, optional voxel-mask filter, duplicates summed,
+        explicit zeros kept.  Meant for small volumes (N <= 128): 8 slots per sample."""
+        from scipy import sparse
+        f, be = self._fwd, self.backend
+        n_proj = f.poses.shape[0]
+        W, DET, DAT = [], [], []
+        total = 0
+        for ip in range(n_proj):
+            dat, det, wts = be.triplets(f.poses[ip:ip + 1])
+            total += dat.size
+            if total > max_nnz:
+                raise MemoryError("tocsr: more than %d triplets; keep the operator matrix-free" % max_nnz)
+            W.append(wts.astype(f.precision, copy=False))                       # :106
+            DAT.append(dat)
+            DET.append(det.astype(np.int64) + ip * be.n_det)                    # :108
+        W, DET, DAT = np.concatenate(W), np.concatenate(DET), np.concatenate(DAT)
+        if f._mask is not None:                                                 # :60-70
+            m = be.download(f._mask).astype(bool)[DAT]
+            if not m.any():
+                W = W * 0.0
+            else:
+                DAT, DET, W = DAT[m], DET[m], W[m]
+        A = sparse.csr_matrix(sparse.coo_matrix((W, (DET, DAT)), shape=f.shape))  # :73-76
+        return A.T.tocsr() if self._is_adjoint else A
 
 
 class ProjectionMatrix(object):
@@ -181,6 +205,22 @@ class ProjectionMatrix(object):
             cor = cor[:n_proj]      # the reference indexes cor_shift[iproj] (utilities/projection_operators.py:102)
         poses = _lib.poses_array(phi, alpha, beta, xyz_shift, cor)
         return RayOperator(self.backend, poses, self.precision, voxel_mask)
+
+    def _forward_voxel(self):
+        """Per-projection triplets of the voxel-driven splat (reference utilities/projection_operators.py:78-93; never
+        called there, :54).  Needs projection_matrix() to have set angles / xyz_shift first."""
+        import copy
+        from . import voxel_utilities
+        weights, detector_inds, data_inds = [], [], []
+        for iproj in range(self.n_proj):
+            this_geo = copy.copy(self.geometry)
+            this_geo.cor_shift = np.asarray(self.geometry.cor_shift)[iproj]
+            phi, alpha, beta = self.angles[iproj]
+            dat, det, wts = voxel_utilities.forward_sparse(this_geo, alpha, beta, phi, self.xyz_shift[iproj], backend=self.backend)
+            weights.append(wts.astype(self.precision, copy=False))
+            detector_inds.append((det + iproj * int(self.geometry.n_det)).astype(np.int32))
+            data_inds.append(dat)
+        return weights, detector_inds, data_inds
 
     # ---- volume residency for repeated projection_gradient calls (alignment inner loop)
     def set_volume(self, rec):
