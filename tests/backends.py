@@ -10,9 +10,14 @@ from oracle import oracle as orc
 class Buf(object):
     """Host 'device buffer': same tiny surface as _lib.DeviceArray."""
 
-    def __init__(self, a):
-        self.a = np.ascontiguousarray(a, np.float32).ravel().copy()
+    def __init__(self, a, copy=True):
+        self.a = np.ascontiguousarray(a, np.float32).ravel()
+        if copy:
+            self.a = self.a.copy()
         self.size = self.a.size
+
+    def view(self, offset, n):
+        return Buf(self.a[offset:offset + n], copy=False)
 
     def download(self):
         return self.a.copy()
@@ -170,6 +175,13 @@ class GlooComm(object):
         t = torch.tensor([float(v)], dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t[0])
+
+    def allreduce_array(self, a):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a, np.float64))
+        self.dist.all_reduce(t)
+        a[...] = t.numpy()
+        return a
 
     def barrier(self):
         self.dist.barrier()

@@ -1,0 +1,189 @@
+"""
+Batched per-projection pose alignment: the inner loop of the reference's examples/align_rigid.py:40-52
+(for every projection: scipy L-BFGS-B on cost_xzab / gradient_xzab with bounds) with all projections'
+optimisers advancing together, so that each round of function evaluations is ONE launch of the fused
+cost/gradient kernel over many projections (tomo_cost_grad) instead of n_proj separate launches.
+
+scipy's L-BFGS-B is kept as the optimiser (drop-in semantics): every projection runs its own
+`optimize.minimize` in a worker thread; an evaluation request blocks until the scheduler has collected the pending
+requests of all live workers, evaluated them in one batch and handed the results back.
+
+Multi-GPU: projections are independent -- rank r aligns np.array_split(arange(n_proj), P)[r] with a
+replicated volume and no collective inside the optimiser; the 4 recovered parameters per projection are gathered
+once at the end (an all-reduce of a zero-padded table).
+"""
+import threading
+
+import numpy as np
+from scipy import optimize
+
+try:
+    from . import _lib
+except ImportError:
+    import _lib
+
+# parameter letters -> pose columns (phi, alpha, beta, tx, ty, tz, cor_x) and Jacobian rows (tx,ty,tz,phi,alpha,beta)
+_POSE_COL = {"x": 3, "y": 4, "z": 5, "p": 0, "a": 1, "b": 2}
+_GRAD_ROW = {"x": 0, "y": 1, "z": 2, "p": 3, "a": 4, "b": 5}
+
+
+class BatchEvaluator(object):
+    """cost / gradient of many projections per launch, volume and measured projections resident in HBM."""
+
+    def __init__(self, backend, rec, projections, cor_shift=None):
+        self.be = backend
+        self.vol = rec if backend.is_buffer(rec) else backend.upload(np.asarray(rec, np.float32).ravel())
+        b = np.asarray(projections, np.float32)
+        self.n = b.shape[0]
+        self.b_host = b.reshape(self.n, -1)
+        self._b_all = backend.upload(self.b_host)
+        self.cor = np.zeros(self.n) if cor_shift is None else np.asarray(cor_shift, np.float64).reshape(self.n, -1)[:, 0]
+        self._gather = None
+        self.n_launch = 0
+        self.n_eval = 0
+
+    def evaluate(self, idx, poses6):
+        """idx: projection indices (m,), poses6: (m,6) rows (phi, alpha, beta, tx, ty, tz) -> cost[m], grad6[m,6]."""
+        idx = np.asarray(idx, np.int64)
+        m = idx.size
+        poses = np.zeros((m, _lib.POSE_STRIDE), np.float64)
+        poses[:, :6] = poses6
+        poses[:, 6] = self.cor[idx]
+        n_det = self.be.n_det
+        if m == self.n and np.array_equal(idx, np.arange(self.n)):
+            b = self._b_all
+        else:
+            if self._gather is None or self._gather.size < m * n_det:
+                self._gather = self.be.empty(max(m, 16) * n_det)
+            b = self._gather.view(0, m * n_det)
+            b.upload(self.b_host[idx])            # host-side gather of the active rows (few MB per round)
+        self.n_launch += 1
+        self.n_eval += m
+        return self.be.cost_grad(np.ascontiguousarray(poses), self.vol, b)
+
+
+class _Scheduler(object):
+    """Collects one pending request per live worker, evaluates them in one batch, releases the workers."""
+
+    def __init__(self, evaluator, n_workers):
+        self.ev = evaluator
+        self.cv = threading.Condition()
+        self.live = n_workers
+        self.pending = {}
+        self.results = {}
+        self.error = None
+
+    def request(self, i, pose6):
+        with self.cv:
+            self.pending[i] = pose6
+            self.cv.notify_all()
+            while i not in self.results and self.error is None:
+                self.cv.wait()
+            if self.error is not None:
+                raise self.error
+            return self.results.pop(i)
+
+    def done(self):
+        with self.cv:
+            self.live -= 1
+            self.cv.notify_all()
+
+    def run(self):
+        while True:
+            with self.cv:
+                while self.live > 0 and len(self.pending) < self.live:
+                    self.cv.wait()
+                if self.live == 0 and not self.pending:
+                    return
+                idx = sorted(self.pending)
+                poses = np.array([self.pending[i] for i in idx])
+                self.pending.clear()
+            try:
+                cost, g6 = self.ev.evaluate(idx, poses)
+            except Exception as e:                      # release the workers, re-raise in the caller
+                with self.cv:
+                    self.error = e
+                    self.cv.notify_all()
+                raise
+            with self.cv:
+                for k, i in enumerate(idx):
+                    self.results[i] = (float(cost[k]), g6[k].copy())
+                self.cv.notify_all()
+
+
+def align_projections(backend, rec, projections, phi, letters="xzab", x0=None, angles0=None, xyz0=None, cor_shift=None,
+                      bounds=None, scale_factor=None, options=None, indices=None, max_threads=256):
+    """Align many projections at once.
+
+    letters   which pose components are free, reference naming (utilities/alignment_functions.py): "xzab" = tx, tz,
+              alpha, beta (the pair examples/align_rigid.py:46-49 minimises), "xzpab", "xz", ...
+    x0        (n, len(letters)) start values (default 0); angles0 (n,3) fixed (phi,alpha,beta) offsets (default
+              phi from `phi`, 0, 0); xyz0 (n,3) fixed translations.
+    bounds    per-parameter (lo, hi) pairs as scipy takes them (examples/align_rigid.py:48 uses +-3 px / +-0.02 rad).
+    Returns dict(x=(n,k), fun=(n,), nfev=(n,), n_launch, n_eval).
+    """
+    b = np.asarray(projections, np.float32)
+    n_all = b.shape[0]
+    indices = np.arange(n_all) if indices is None else np.asarray(indices, np.int64)
+    k = len(letters)
+    cols = [_POSE_COL[c] for c in letters]
+    rows = [_GRAD_ROW[c] for c in letters]
+    scale = np.ones(k) if scale_factor is None else np.asarray(scale_factor, np.float64)
+    base = np.zeros((n_all, 6))
+    base[:, 0] = np.asarray(phi, np.float64)
+    if angles0 is not None:
+        base[:, 0:3] = np.asarray(angles0, np.float64)
+    if xyz0 is not None:
+        base[:, 3:6] = np.asarray(xyz0, np.float64)
+    x0 = np.zeros((n_all, k)) if x0 is None else np.asarray(x0, np.float64).reshape(n_all, k)
+    ev = BatchEvaluator(backend, rec, b, cor_shift)
+    out_x, out_f, out_n = np.zeros((n_all, k)), np.zeros(n_all), np.zeros(n_all, np.int64)
+    opts = {"disp": False}
+    opts.update(options or {})
+
+    for c0 in range(0, indices.size, max_threads):
+        chunk = indices[c0:c0 + max_threads]
+        sched = _Scheduler(ev, chunk.size)
+        errors = []
+
+        def work(i):
+            try:
+                def fun(p):
+                    pose = base[i].copy()
+                    pose[cols] += p
+                    cost, g6 = sched.request(i, pose)
+                    return cost, g6[rows] * scale
+                res = optimize.minimize(fun, x0[i], jac=True, method="L-BFGS-B", bounds=bounds, options=opts)
+                out_x[i], out_f[i], out_n[i] = res.x, res.fun, res.nfev
+            except Exception as e:      # noqa: BLE001
+                errors.append(e)
+            finally:
+                sched.done()
+
+        threads = [threading.Thread(target=work, args=(int(i),), daemon=True) for i in chunk]
+        for t in threads:
+            t.start()
+        sched.run()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+    return {"x": out_x, "fun": out_f, "nfev": out_n, "n_launch": ev.n_launch, "n_eval": ev.n_eval}
+
+
+def align_projections_sharded(comm, backend, rec, projections, phi, **kw):
+    """Rank r aligns its np.array_split block of the projections; every rank returns the full (n, k) table."""
+    n = np.asarray(projections).shape[0]
+    size = comm.Get_size() if hasattr(comm, "Get_size") else comm.size
+    rank = comm.Get_rank() if hasattr(comm, "Get_rank") else comm.rank
+    mine = np.array_split(np.arange(n), size)[rank]
+    res = align_projections(backend, rec, projections, phi, indices=mine, **kw)
+    k = res["x"].shape[1]
+    table = np.zeros((n, k + 2))
+    table[mine, :k] = res["x"][mine]
+    table[mine, k] = res["fun"][mine]
+    table[mine, k + 1] = res["nfev"][mine]
+    if size > 1:
+        comm.allreduce_array(table)                      # tiny: k + 2 numbers per projection, zero outside the own block
+    return {"x": table[:, :k], "fun": table[:, k], "nfev": table[:, k + 1].astype(np.int64), "n_launch": res["n_launch"],
+            "n_eval": res["n_eval"]}

@@ -41,6 +41,9 @@ class SingleComm(object):
     def allreduce_max(self, v):
         return v
 
+    def allreduce_array(self, a):
+        return a
+
     def barrier(self):
         pass
 
@@ -119,6 +122,13 @@ class RcclComm(object):
         a = np.array([v], np.float64)
         self.ctx.check(self.ctx.lib.tomo_allreduce_max_f64_host(self.ctx.handle, _lib.dptr(a), 1))
         return float(a[0])
+
+    def allreduce_array(self, a):
+        """Element-wise sum of a small float64 host array across ranks (in place)."""
+        flat = np.ascontiguousarray(a, np.float64).ravel()
+        self.ctx.check(self.ctx.lib.tomo_allreduce_sum_f64_host(self.ctx.handle, _lib.dptr(flat), flat.size))
+        a[...] = flat.reshape(a.shape)
+        return a
 
     def barrier(self):
         self.allreduce_scalar(0.0)

@@ -32,13 +32,17 @@ def run(N, n_proj, what, tilt=True, reps=2, opts=None):
     vol = be.zeros(N ** 3); be.fill(vol, 1.0)
     prj = be.zeros(n_proj * N * N); be.fill(prj, 1.0)
     P = poses(n_proj, tilt, rng)
+    grad = be.empty(6 * N * N) if what == "pg" else None
     fn = {"fwd": lambda: be.forward(P, vol, prj), "adj": lambda: be.adjoint(P, prj, vol),
-          "bpv": lambda: be.backproject_voxel(P, prj, vol)}[what]
+          "bpv": lambda: be.backproject_voxel(P, prj, vol),
+          "cg": lambda: be.cost_grad(P, vol, prj),
+          "pg": lambda: [be.proj_grad(P[i:i + 1], vol, prj, grad) for i in range(n_proj)]}[what]
     fn(); be.sync()
     best = 1e30
     for _ in range(reps):
         be.ctx.timer_start(); fn(); ms = be.ctx.timer_stop(); best = min(best, ms)
-    alg = {"fwd": 4 * N ** 3 + 4 * N * N, "adj": 8 * N ** 3 + 4 * N * N, "bpv": 8 * N ** 3 + 4 * N * N}[what] * n_proj
+    alg = {"fwd": 4 * N ** 3 + 4 * N * N, "adj": 8 * N ** 3 + 4 * N * N, "bpv": 8 * N ** 3 + 4 * N * N,
+           "cg": 4 * N ** 3 + 4 * N * N + 28, "pg": 4 * N ** 3 + 28 * N * N}[what] * n_proj
     print("%-4s N=%4d n_proj=%4d tilt=%d opts=%s : %9.2f ms  alg %.1f GB/s  (%.1f%% of 8 TB/s)  [%.3f ms/angle]"
           % (what, N, n_proj, tilt, opts, best, alg / best / 1e6, alg / best / 1e6 / 80.0, best / n_proj), flush=True)
     del vol, prj
