@@ -142,3 +142,30 @@ def test_rccl_single_rank_allreduce():
     assert np.array_equal(x.download(), np.arange(1000, dtype=np.float32))
     assert comm.allreduce_scalar(2.5) == 2.5 and comm.allreduce_max(-1.0) == -1.0
     comm.close()
+
+
+def test_example_drivers_recover_misalignment():
+    """generate_data -> align_rigid: the known-answer smoke test the reference's examples amount to."""
+    from tomography_alignment_amd.examples import generate_data, align_rigid
+    data = generate_data.make(size=32, n_proj=24, seed=3)
+    assert data["projections"].shape == (24, 32, 32)
+    rec, a, b, xyz, hist = align_rigid.run(data, n_outer=3, sirt_iters=40, verbose=False)
+    assert hist[-1]["shift_err_px"] < 0.6 * max(hist[0]["shift_err_px"], 1e-9) or hist[-1]["shift_err_px"] < 0.15
+    assert hist[-1]["shift_err_px"] < np.abs(data["xyz"][:, [0, 2]]).mean()        # better than doing nothing
+    assert hist[0]["launches"] < hist[0]["evals"]                                  # evaluations were batched
+
+
+def test_batched_alignment_gpu(shepp32):
+    from oracle import oracle as orc
+    from tomography_alignment_amd import alignment
+    from tomography_alignment_amd.backend import HipBackend
+    n, N = 5, 32
+    rng = np.random.default_rng(22)
+    phi = np.linspace(0.3, 2.8, n)
+    true = np.column_stack([rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), np.deg2rad(rng.uniform(-1, 1, n)), np.deg2rad(rng.uniform(-1, 1, n))])
+    og = orc.Geo(1, np.array([N] * 3), np.ones(3), np.array([N, N]), np.ones(2))
+    b = np.array([orc.projection_gradient(og, shepp32, true[i, 2], true[i, 3], phi[i], np.array([true[i, 0], 0., true[i, 1]]), np.zeros(3))[0]
+                  for i in range(n)])
+    res = alignment.align_projections(HipBackend(geom(n, N)), shepp32, b, phi, letters="xzab",
+                                      bounds=((-3., 3.), (-3., 3.), (-0.02, 0.02), (-0.02, 0.02)))
+    assert np.allclose(res["x"], true, atol=1e-4) and res["n_launch"] < res["n_eval"]
