@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--angles", type=int, default=1024)
     ap.add_argument("--perturbed", action="store_true", help="alpha,beta ~ U(+-1 deg), tx,tz ~ U(+-2 px) (default_rng(0))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-align", action="store_true", help="skip the alignment-gradient evals/s side measurement (config 5)")
     ap.add_argument("--fwd-variant", type=int, default=None)
     ap.add_argument("--adj-variant", type=int, default=None)
     args = ap.parse_args()
@@ -174,12 +175,51 @@ def main():
         step_alg = n_proj * (12.0 * N ** 3 + 8.0 * n_det) + 16.0 * n_proj * n_det + 16.0 * N ** 3
         out["sirt_step_alg_GBps"] = round(step_alg / (elapsed / args.steps) / 1e9, 1)
 
+    if not args.no_align:
+        del solver
+        out["alignment_gradient"] = align_rate(comm, ctx, rank, world)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(be, d_true, N, n_proj, phi)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         comm.close()
+
+
+def align_rate(comm, ctx, rank, world, N=512, n_proj=720, passes=3):
+    """Side measurement (not `value`): alignment cost+gradient evaluations per second on BASELINE config 5 -- 512^3
+    volume, 720 projections with +-2 deg / +-5 px perturbations (default_rng(5)); projections are sharded over the
+    ranks with a replicated volume and no collective; one fused launch evaluates a rank's whole shard."""
+    from tomography_alignment_amd import _lib
+    from tomography_alignment_amd.backend import HipBackend
+    from tomography_alignment_amd.utilities.geometry import Geometry
+    from tomography_alignment_amd.utilities.generate_phantom import SHEPP_LOGAN
+    rng = np.random.default_rng(5)
+    phi = np.linspace(0., np.pi, n_proj)
+    alpha, beta = np.deg2rad(rng.uniform(-2, 2, n_proj)), np.deg2rad(rng.uniform(-2, 2, n_proj))
+    xyz = np.zeros((n_proj, 3))
+    xyz[:, 0], xyz[:, 2] = rng.uniform(-5, 5, n_proj), rng.uniform(-5, 5, n_proj)
+    mine = np.array_split(np.arange(n_proj), world)[rank]
+    geo = Geometry(mine.size, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
+    be = HipBackend(geo, ctx=ctx)
+    vol = be.phantom(be.empty(N ** 3), (N, N, N), SHEPP_LOGAN)
+    truth = _lib.poses_array(phi[mine], alpha[mine], beta[mine], xyz[mine], np.zeros(3))
+    b = be.forward(truth, vol, be.empty(mine.size * N * N))
+    start = _lib.poses_array(phi[mine], 0 * alpha[mine], 0 * beta[mine], 0 * xyz[mine], np.zeros(3))   # evaluate at the unaligned start
+    be.cost_grad(start, vol, b)
+    ctx.sync()
+    comm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        cost, g6 = be.cost_grad(start, vol, b)
+    ctx.sync()
+    comm.barrier()
+    dt = comm.allreduce_max(time.perf_counter() - t0)
+    rate = passes * n_proj / dt
+    alg = 4.0 * N ** 3 + 4.0 * N * N + 28.0                      # fused form, BASELINE.md section 3
+    return {"evals_per_sec": round(rate, 1), "unit": "evals/s", "config": "%d^3 volume, %d projections, +-2 deg / +-5 px, fused cost+6-DoF gradient"
+            % (N, n_proj), "alg_GBps": round(rate * alg / 1e9, 1), "frac_of_hbm_peak": round(rate * alg / 1e9 / HBM_PEAK_GBS, 4),
+            "projections_per_launch": int(mine.size), "cost_first": float(cost[0])}
 
 
 def cpu_baseline(be, d_true, N, n_proj, phi):

@@ -132,6 +132,8 @@ def test_vector_kernels_phantom_timer_profile():
 
 
 def test_rccl_single_rank_allreduce():
+    import os
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")      # single node: bootstrap over loopback (no NIC probing)
     from tomography_alignment_amd import _lib
     from tomography_alignment_amd.comm import RcclComm
     ctx = _lib.Context(0)
@@ -150,8 +152,8 @@ def test_example_drivers_recover_misalignment():
     data = generate_data.make(size=32, n_proj=24, seed=3)
     assert data["projections"].shape == (24, 32, 32)
     rec, a, b, xyz, hist = align_rigid.run(data, n_outer=3, sirt_iters=40, verbose=False)
-    assert hist[-1]["shift_err_px"] < 0.6 * max(hist[0]["shift_err_px"], 1e-9) or hist[-1]["shift_err_px"] < 0.15
-    assert hist[-1]["shift_err_px"] < np.abs(data["xyz"][:, [0, 2]]).mean()        # better than doing nothing
+    doing_nothing = np.abs(data["xyz"][:, [0, 2]]).mean()                          # ~1 px of injected jitter
+    assert hist[-1]["shift_err_px"] < 0.3 * doing_nothing and hist[-1]["shift_err_px"] <= hist[0]["shift_err_px"]
     assert hist[0]["launches"] < hist[0]["evals"]                                  # evaluations were batched
 
 

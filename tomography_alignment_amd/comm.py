@@ -83,6 +83,8 @@ class RcclComm(object):
             c = SingleComm()
             c.ctx = ctx
             return c
+        # one node (the launch contract is --nnodes=1): let RCCL bootstrap over loopback instead of probing NICs
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         key = "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
         path = os.path.join(tempfile.gettempdir(), "tomo_rccl_%s.id" % key)
         if rank == 0:
