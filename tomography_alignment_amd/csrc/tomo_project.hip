@@ -281,6 +281,7 @@ __global__ __launch_bounds__(256) void k_adj_v1(const ProjC *__restrict__ pcs, c
 struct AdjC {
     double p0[3], u[3], w[3], d[3];
     double minv[3][3];   // (ix, iz, j) = minv * (p - p0)
+    int64_t fp0[3], fu[3], fw[3], fd[3];   // the same lattice in 32.32 fixed point (index space)
     int32_t n, pad_;
 };
 
@@ -301,10 +302,26 @@ __device__ __forceinline__ int cvt_round_i32(float x)
     return r;
 }
 
+// trilinear value with the lerps ordered y -> x -> z so that the (z, z+1) register pairs ds_read2_b32 returns feed the
+// packed ops directly: p00 = (v000, v001), p01 = (v010, v011), p10 = (v100, v101), p11 = (v110, v111)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float trilerp_pairs(f32x2 p00, f32x2 p01, f32x2 p10, f32x2 p11, float wx, float wy, float wz)
+{
+    const f32x2 c0 = p00 + wy * (p01 - p00);
+    const f32x2 c1 = p10 + wy * (p11 - p10);
+    const f32x2 e = c0 + wx * (c1 - c0);
+    return fmaf(wz, e.y - e.x, e.x);
+}
+
 // FWD = true : the LDS image holds the volume tile (+1 high-side halo, zeros outside the volume); owned samples are
 //              interpolated from it with ds_read and each (tile, projection, detector row) adds its partial ray sums to
 //              proj with one 256-B global float atomic per wave -- the volume is read from HBM once per CALL, not per angle.
 // FWD = false: the adjoint described above.
+//
+// Sample positions are 32.32 FIXED POINT (int64): p = fp0 + ix*fu + iz*fw + j*fd - tile_origin.  Integer arithmetic is
+// exact and order-independent, so every tile computes the identical cell and fraction for a sample (consistent ownership,
+// A^T uses exactly A's weights) without any float64 work in the kernel; resolution 2^-32 voxel, accumulated rounding of the
+// lattice constants < 1e-6 voxel at 1024^3.
 template <bool FWD>
 __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
                                                          float *__restrict__ vol, TomoGeomC g, const unsigned *__restrict__ absmax_bits,
@@ -336,29 +353,39 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
         for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) acc[e] = 0;
         __syncthreads();
     }
-    const double blo[3] = {(double)x0, (double)y0, (double)z0};
-    const double bhi[3] = {(double)(x0 + ATX), (double)(y0 + ATY), (double)(z0 + ATZ)};
+    const float bc[3] = {(float)x0 + 0.5f * ATX, (float)y0 + 0.5f * ATY, (float)z0 + 0.5f * ATZ};   // owned-box centre
+    const float ext[3] = {(float)ATX, (float)ATY, (float)ATZ};
+    const int64_t org[3] = {(int64_t)x0 << 32, (int64_t)y0 << 32, (int64_t)z0 << 32};
     const size_t n_det = (size_t)g.ndx * g.ndz;
+    const float two_m32 = 2.3283064365386963e-10f;
 
     const int batch = FWD ? n_proj : ADJ_BATCH;
     for (int ip0 = 0; ip0 < n_proj; ip0 += batch) {
         const int ip1 = min(n_proj, ip0 + batch);
         for (int ip = ip0; ip < ip1; ++ip) {
             const AdjC &c = pcs[ip];
+            // Range work is CONSERVATIVE set-up in float32 (coordinates < 2^11: float32 error < 1e-3 voxel, margins 2e-2): it
+            // only has to cover the owned samples; exact ownership is decided per sample from the fixed-point position.
             // lattice-coordinate ranges of the owned box: a linear functional over a box = centre value +- sum |coef|*half-extent
-            const double qx = 0.5 * (blo[0] + bhi[0]) - c.p0[0], qy = 0.5 * (blo[1] + bhi[1]) - c.p0[1], qz = 0.5 * (blo[2] + bhi[2]) - c.p0[2];
-            const double ixc = c.minv[0][0] * qx + c.minv[0][1] * qy + c.minv[0][2] * qz;
-            const double ixr = fabs(c.minv[0][0]) * (0.5 * ATX) + fabs(c.minv[0][1]) * (0.5 * ATY) + fabs(c.minv[0][2]) * (0.5 * ATZ);
-            const double izm = c.minv[1][0] * qx + c.minv[1][1] * qy + c.minv[1][2] * qz;
-            const double izr = fabs(c.minv[1][0]) * (0.5 * ATX) + fabs(c.minv[1][1]) * (0.5 * ATY) + fabs(c.minv[1][2]) * (0.5 * ATZ);
-            const int ix_lo = max(0, (int)ceil(fmax(ixc - ixr, -1.0) - 1e-6));
-            const int ix_hi = min(g.ndx - 1, (int)floor(fmin(ixc + ixr, (double)g.ndx) + 1e-6));
+            const float qx = bc[0] - (float)c.p0[0], qy = bc[1] - (float)c.p0[1], qz = bc[2] - (float)c.p0[2];
+            const float m00 = (float)c.minv[0][0], m01 = (float)c.minv[0][1], m02 = (float)c.minv[0][2];
+            const float m10 = (float)c.minv[1][0], m11 = (float)c.minv[1][1], m12 = (float)c.minv[1][2];
+            const float ixc = m00 * qx + m01 * qy + m02 * qz;
+            const float ixr = fabsf(m00) * (0.5f * ATX) + fabsf(m01) * (0.5f * ATY) + fabsf(m02) * (0.5f * ATZ) + 2e-2f;
+            const float izm = m10 * qx + m11 * qy + m12 * qz;
+            const float izr = fabsf(m10) * (0.5f * ATX) + fabsf(m11) * (0.5f * ATY) + fabsf(m12) * (0.5f * ATZ) + 2e-2f;
+            const int ix_lo = max(0, (int)ceilf(fmaxf(ixc - ixr, -1.f)));
+            const int ix_hi = min(g.ndx - 1, (int)floorf(fminf(ixc + ixr, (float)g.ndx)));
             if (ix_lo > ix_hi) continue;
-            const double izl = fmax(izm - izr, 0.0), izh = fmin(izm + izr, (double)(g.ndz - 1));
-            if (izl > izh + 1.0) continue;
-            const double izc = 0.5 * (izl + izh), hs = 0.5 * (izh - izl) + 1.0;   // lanes' iz spread about the centre line
-            const float dxf = (float)c.d[0], dyf = (float)c.d[1], dzf = (float)c.d[2];
+            const float izl = fmaxf(izm - izr, 0.f), izh = fminf(izm + izr, (float)(g.ndz - 1));
+            if (izl > izh + 1.f) continue;
+            const float izc = 0.5f * (izl + izh), hs = 0.5f * (izh - izl) + 1.f;   // lanes' iz spread about the centre line
             const int n_rows_w = (ix_hi - ix_lo - wv) >= 0 ? (ix_hi - ix_lo - wv) / ADJ_WAVES + 1 : 0;   // this wave's rows
+            const float fp0[3] = {(float)c.p0[0] - (float)x0, (float)c.p0[1] - (float)y0, (float)c.p0[2] - (float)z0};   // tile-relative
+            const float fu[3] = {(float)c.u[0], (float)c.u[1], (float)c.u[2]}, fw[3] = {(float)c.w[0], (float)c.w[1], (float)c.w[2]};
+            const float fd[3] = {(float)c.d[0], (float)c.d[1], (float)c.d[2]};
+            // per-lane part of the fixed-point position: lane * fw  (the row adds the uniform rest)
+            const int64_t lw0 = (int64_t)lane * c.fw[0], lw1 = (int64_t)lane * c.fw[1], lw2 = (int64_t)lane * c.fw[2];
 
             for (int r0 = 0; r0 < n_rows_w; r0 += 64) {
                 // row set-up, one detector row per LANE (row r0+lane of this wave), broadcast below with v_readlane:
@@ -367,77 +394,91 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
                 int v_jlo = 0, v_jhi = 0, v_izf = 0, v_izl = -1;
                 {
                     const int rix = ix_lo + wv + ADJ_WAVES * (r0 + lane);
-                    double t0 = 0.0, t1 = (double)(c.n - 1);
+                    const float frix = (float)rix;
+                    float t0 = 0.f, t1 = (float)(c.n - 1);
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
-                        const double cb = c.p0[a] + (double)rix * c.u[a] + izc * c.w[a];
-                        const double h = fabs(c.w[a]) * hs + 1e-5;
-                        tomo_clip_axis(cb, c.d[a], blo[a] - h, bhi[a] + h, t0, t1);
+                        const float cb = fp0[a] + frix * fu[a] + izc * fw[a];          // tile-relative centre-line point at j = 0
+                        const float h = fabsf(fw[a]) * hs + 2e-2f;
+                        const float lo_a = -h, hi_a = ext[a] + h;
+                        if (fd[a] != 0.f) {
+                            const float inv = 1.f / fd[a];
+                            const float ta = (lo_a - cb) * inv, tb = (hi_a - cb) * inv;
+                            t0 = fmaxf(t0, fminf(ta, tb));
+                            t1 = fminf(t1, fmaxf(ta, tb));
+                        } else if (cb < lo_a || cb >= hi_a) {
+                            t0 = 1.f; t1 = 0.f;
+                        }
                     }
                     if (rix <= ix_hi && t0 <= t1) {
-                        v_jlo = max(0, (int)ceil(t0 - 1e-6));
-                        v_jhi = min(c.n, (int)floor(t1 + 1e-6) + 1);
-                        const double cz = c.p0[2] + (double)rix * c.u[2];
-                        const double zj0 = (double)v_jlo * c.d[2], zj1 = (double)(v_jhi - 1) * c.d[2];
-                        const double iw = 1.0 / c.w[2];
-                        v_izf = max(0, (int)floor((blo[2] - cz - fmax(zj0, zj1)) * iw - 1e-5));
-                        v_izl = min(g.ndz - 1, (int)ceil((bhi[2] - cz - fmin(zj0, zj1)) * iw + 1e-5));
+                        v_jlo = max(0, (int)ceilf(t0));                              // the 2e-2 box margin already covers float32 error
+                        v_jhi = min(c.n, (int)floorf(t1) + 1);
+                        const float czr = fp0[2] + frix * fu[2];                       // z0-relative
+                        const float zj0 = (float)v_jlo * fd[2], zj1 = (float)(v_jhi - 1) * fd[2];
+                        const float iw = 1.f / fw[2];
+                        v_izf = max(0, (int)floorf((0.f - czr - fmaxf(zj0, zj1)) * iw - 2e-2f));
+                        v_izl = min(g.ndz - 1, (int)ceilf((ext[2] - czr - fminf(zj0, zj1)) * iw + 2e-2f));
                     }
                 }
                 const int r_end = min(64, n_rows_w - r0);
                 for (int r = 0; r < r_end; ++r) {
-                const int jlo = __builtin_amdgcn_readlane(v_jlo, r), jhi = __builtin_amdgcn_readlane(v_jhi, r);
-                if (jhi <= jlo) continue;
-                const int iz_first = __builtin_amdgcn_readlane(v_izf, r), iz_last = __builtin_amdgcn_readlane(v_izl, r);
-                const int ix = ix_lo + wv + ADJ_WAVES * (r0 + r);
-                for (int izb = iz_first; izb <= iz_last; izb += 64) {
-                    const int iz = izb + lane;
-                    const bool lane_ok = iz <= iz_last;
-                    const int izk = lane_ok ? iz : iz_last;
-                    float *pr = proj + (size_t)ip * n_det + (size_t)ix * g.ndz + izk;
-                    const float ys = FWD ? 0.f : (lane_ok ? *pr : 0.f) * scale;
-                    float part = 0.f;
-                    bool touched = false;
-                    double b[3];
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) b[a] = c.p0[a] + (double)ix * c.u[a] + (double)izk * c.w[a];
-                    for (int jb = jlo & ~(TOMO_TILE_JB - 1); jb < jhi; jb += TOMO_TILE_JB) {
-                        int ia[3];
-                        float f0[3];
-                        tomo_block_anchor(b, c.d, jb, ia, f0, TOMO_TILE_JB);   // tile-independent: same bits in every tile
-                        const int ox = ia[0] - x0, oy = ia[1] - y0, oz = ia[2] - z0;
-                        const int lo = max(jlo, jb) - jb, hi = min(jhi, jb + TOMO_TILE_JB) - jb;
-                        for (int jj = lo; jj < hi; ++jj) {
-                            const float t = (float)jj;
-                            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
-                            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-                            const int lx = ox + (int)fx, ly = oy + (int)fy, lz = oz + (int)fz;
-                            if (lane_ok && (unsigned)lx < (unsigned)ATX && (unsigned)ly < (unsigned)ATY && (unsigned)lz < (unsigned)ATZ) {
-                                const float wcx = x - fx, wcy = y - fy, wcz = z - fz;
-                                if (FWD) {
-                                    const float *q = &img[(int)(__umul24((unsigned)lx, ALY) + (unsigned)ly) * ALZ + lz];
-                                    part += trilerp(q[0], q[1], q[ALZ], q[ALZ + 1], q[ALY * ALZ], q[ALY * ALZ + 1], q[ALY * ALZ + ALZ],
-                                                    q[ALY * ALZ + ALZ + 1], wcx, wcy, wcz);
-                                    touched = true;
-                                    continue;
+                    const int jlo = __builtin_amdgcn_readlane(v_jlo, r), jhi = __builtin_amdgcn_readlane(v_jhi, r);
+                    if (jhi <= jlo) continue;
+                    const int iz_first = __builtin_amdgcn_readlane(v_izf, r), iz_last = __builtin_amdgcn_readlane(v_izl, r);
+                    const int ix = ix_lo + wv + ADJ_WAVES * (r0 + r);
+                    // uniform part of the fixed-point position of sample jlo of this row (scalar 64-bit arithmetic)
+                    const int64_t rb0 = c.fp0[0] + (int64_t)ix * c.fu[0] + (int64_t)jlo * c.fd[0] - org[0];
+                    const int64_t rb1 = c.fp0[1] + (int64_t)ix * c.fu[1] + (int64_t)jlo * c.fd[1] - org[1];
+                    const int64_t rb2 = c.fp0[2] + (int64_t)ix * c.fu[2] + (int64_t)jlo * c.fd[2] - org[2];
+                    const int cnt = jhi - jlo;
+                    for (int izb = iz_first; izb <= iz_last; izb += 64) {
+                        const int iz = izb + lane;
+                        const bool lane_ok = iz <= iz_last;
+                        float *pr = proj + (size_t)ip * n_det + (size_t)ix * g.ndz + iz;
+                        int64_t px = rb0 + (int64_t)izb * c.fw[0] + lw0;
+                        int64_t py = rb1 + (int64_t)izb * c.fw[1] + lw1;
+                        int64_t pz = rb2 + (int64_t)izb * c.fw[2] + lw2;
+                        if (FWD) {
+                            // branch-free body (lanes that do not own the sample read LDS word 0 and discard it), so the compiler
+                            // can overlap the LDS latency of consecutive samples
+                            float part = 0.f;
+                            for (int jj = 0; jj < cnt; ++jj) {
+                                const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32), lz = (unsigned)(pz >> 32);
+                                static_assert(ATX == ATY && (ATX & (ATX - 1)) == 0, "ownership test uses (lx | ly) < ATX");
+                                const bool own = (lx | ly) < (unsigned)ATX && lz < (unsigned)ATZ;
+                                const unsigned e = own ? __umul24(lx, ALY * ALZ) + __umul24(ly, ALZ) + lz : 0u;
+                                const float wx = (float)(unsigned)px * two_m32, wy = (float)(unsigned)py * two_m32, wz = (float)(unsigned)pz * two_m32;
+                                const float *q = img + e;
+                                const f32x2 p00 = {q[0], q[1]}, p01 = {q[ALZ], q[ALZ + 1]};
+                                const f32x2 p10 = {q[ALY * ALZ], q[ALY * ALZ + 1]}, p11 = {q[ALY * ALZ + ALZ], q[ALY * ALZ + ALZ + 1]};
+                                const float v = trilerp_pairs(p00, p01, p10, p11, wx, wy, wz);
+                                part += own ? v : 0.f;
+                                px += c.fd[0]; py += c.fd[1]; pz += c.fd[2];
+                            }
+                            if (lane_ok) atomicAdd(pr, part);          // 64 consecutive floats per wave: the full-rate atomic shape
+                        } else {
+                            const float ys = (lane_ok ? *pr : 0.f) * scale;
+                            for (int jj = 0; jj < cnt; ++jj) {
+                                const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32), lz = (unsigned)(pz >> 32);
+                                if (lane_ok && (lx | ly) < (unsigned)ATX && lz < (unsigned)ATZ) {
+                                    const float wcx = (float)(unsigned)px * two_m32, wcy = (float)(unsigned)py * two_m32, wcz = (float)(unsigned)pz * two_m32;
+                                    const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
+                                    const float a0 = ys * wfx, a1 = ys * wcx;
+                                    const float b00 = a0 * wfy, b01 = a0 * wcy, b10 = a1 * wfy, b11 = a1 * wcy;
+                                    int *q = &acc[__umul24(lx, ALY * ALZ) + __umul24(ly, ALZ) + lz];
+                                    atomicAdd(q, cvt_round_i32(b00 * wfz));
+                                    atomicAdd(q + 1, cvt_round_i32(b00 * wcz));
+                                    atomicAdd(q + ALZ, cvt_round_i32(b01 * wfz));
+                                    atomicAdd(q + ALZ + 1, cvt_round_i32(b01 * wcz));
+                                    atomicAdd(q + ALY * ALZ, cvt_round_i32(b10 * wfz));
+                                    atomicAdd(q + ALY * ALZ + 1, cvt_round_i32(b10 * wcz));
+                                    atomicAdd(q + ALY * ALZ + ALZ, cvt_round_i32(b11 * wfz));
+                                    atomicAdd(q + ALY * ALZ + ALZ + 1, cvt_round_i32(b11 * wcz));
                                 }
-                                const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
-                                const float a0 = ys * wfx, a1 = ys * wcx;
-                                const float b00 = a0 * wfy, b01 = a0 * wcy, b10 = a1 * wfy, b11 = a1 * wcy;
-                                int *q = &acc[(int)(__umul24((unsigned)lx, ALY) + (unsigned)ly) * ALZ + lz];
-                                atomicAdd(q, cvt_round_i32(b00 * wfz));
-                                atomicAdd(q + 1, cvt_round_i32(b00 * wcz));
-                                atomicAdd(q + ALZ, cvt_round_i32(b01 * wfz));
-                                atomicAdd(q + ALZ + 1, cvt_round_i32(b01 * wcz));
-                                atomicAdd(q + ALY * ALZ, cvt_round_i32(b10 * wfz));
-                                atomicAdd(q + ALY * ALZ + 1, cvt_round_i32(b10 * wcz));
-                                atomicAdd(q + ALY * ALZ + ALZ, cvt_round_i32(b11 * wfz));
-                                atomicAdd(q + ALY * ALZ + ALZ + 1, cvt_round_i32(b11 * wcz));
+                                px += c.fd[0]; py += c.fd[1]; pz += c.fd[2];
                             }
                         }
                     }
-                    if (FWD && touched) atomicAdd(pr, part);          // 64 consecutive floats per wave: the full-rate atomic shape
-                }
                 }
             }
         }
@@ -671,6 +712,16 @@ static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, b
         }
         a.n = pc.n;
         a.pad_ = 0;
+        bool fits = true;
+        for (int r = 0; r < 3; ++r) {
+            const double lim = 1073741824.0;     // |coordinate| < 2^30 voxels
+            fits = fits && fabs(pc.p0[r]) < lim && fabs(pc.u[r]) * g.ndx < lim && fabs(pc.w[r]) * g.ndz < lim && fabs(pc.d[r]) * pc.n < lim;
+            a.fp0[r] = llround(pc.p0[r] * 4294967296.0);
+            a.fu[r] = llround(pc.u[r] * 4294967296.0);
+            a.fw[r] = llround(pc.w[r] * 4294967296.0);
+            a.fd[r] = llround(pc.d[r] * 4294967296.0);
+        }
+        if (!fits) return TOMO_OK;
         if (!invert3(m, a.minv, &det)) return TOMO_OK;
         if (!(pc.w[2] > 0.7 * sqrt(pc.w[0] * pc.w[0] + pc.w[1] * pc.w[1] + pc.w[2] * pc.w[2]))) return TOMO_OK;
         // samples per unit volume = 1/|det[u w d]|; the tent weights a voxel collects from one projection sum to about
