@@ -53,3 +53,17 @@ def test_angle_split_is_the_reference_split():
     assert [len(r) for r in rows] == [3, 3, 2, 2]
     sh = sirt_mpi.SIRT._shard_geometry(geo, rows[2])
     assert sh.n_proj == 2 and np.array_equal(sh.cor_shift, geo.cor_shift[6:8]) and geo.n_proj == 10
+
+
+def test_id_rendezvous_between_processes(tmp_path):
+    """The ncclUniqueId hand-off of RcclComm.from_env (rank 0 publishes, the others poll), with plain bytes."""
+    code = ("import sys, os; sys.path.insert(0, %r)\n"
+            "from tomography_alignment_amd.comm import exchange_from_rank0\n"
+            "r = int(os.environ['RANK'])\n"
+            "got = exchange_from_rank0(r, 3, lambda: bytes(range(128)), timeout=60, directory=%r, key='t')\n"
+            "assert got == bytes(range(128)); print('ok', r)\n") % (ROOT, str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(os.environ, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in (2, 1, 0)]      # the pollers start first
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert sorted(o.strip() for o in outs) == ["ok 0", "ok 1", "ok 2"]

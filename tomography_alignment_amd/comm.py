@@ -21,6 +21,33 @@ except ImportError:      # package directory itself on sys.path
     import _lib
 
 
+def rendezvous_key():
+    """Identifies one launch: the launcher's port and run id plus its pid (all ranks of a node share the parent)."""
+    return "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
+
+
+def exchange_from_rank0(rank, size, make_payload, timeout=300.0, directory=None, key=None):
+    """Rank 0 calls make_payload() and publishes the bytes through a file; every other rank polls for it and reads
+    it.  The file is written atomically (tmp + rename) and left for the ranks to read; stale files of earlier launches
+    cannot collide because the key carries the launcher's pid.  Returns the payload on every rank."""
+    directory = directory or tempfile.gettempdir()
+    path = os.path.join(directory, "tomo_rccl_%s.id" % (key or rendezvous_key()))
+    if rank == 0:
+        payload = make_payload()
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(payload)
+        os.replace(tmp, path)
+        return payload
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > timeout:
+            raise _lib.TomoError("timed out waiting for the RCCL id file %s" % path)
+        time.sleep(0.02)
+    with open(path, "rb") as f:
+        return f.read()
+
+
 class SingleComm(object):
     """World of one: every collective is the identity (the unsharded solvers use this)."""
     size = 1
@@ -85,27 +112,12 @@ class RcclComm(object):
             return c
         # one node (the launch contract is --nnodes=1): let RCCL bootstrap over loopback instead of probing NICs
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-        key = "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
-        path = os.path.join(tempfile.gettempdir(), "tomo_rccl_%s.id" % key)
-        if rank == 0:
-            uid = cls.unique_id(ctx.lib)
-            tmp = path + ".tmp%d" % os.getpid()
-            with open(tmp, "wb") as f:
-                f.write(uid)
-            os.replace(tmp, path)
-        else:
-            t0 = time.time()
-            while not os.path.exists(path):
-                if time.time() - t0 > timeout:
-                    raise _lib.TomoError("timed out waiting for the RCCL id file %s" % path)
-                time.sleep(0.05)
-            with open(path, "rb") as f:
-                uid = f.read()
+        uid = exchange_from_rank0(rank, size, lambda: cls.unique_id(ctx.lib), timeout=timeout)
         comm = cls(ctx, rank, size, uid)
-        comm.barrier()
+        comm.barrier()                  # every rank has joined the communicator, hence has read the id
         if rank == 0:
             try:
-                os.remove(path)
+                os.remove(os.path.join(tempfile.gettempdir(), "tomo_rccl_%s.id" % rendezvous_key()))
             except OSError:
                 pass
         return comm
