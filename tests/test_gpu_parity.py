@@ -293,3 +293,48 @@ def test_voxel_splat_vs_reference_golden(PM):
     P.projection_matrix(alpha=g["alpha"], beta=g["beta"], phi=g["phi"], xyz_shift=g["xyz"])
     wts, dets, dats = P._forward_voxel()
     assert len(wts) == 2 and dets[1].min() >= 256
+
+
+@pytest.mark.parametrize("shape,ndet", [((32, 32, 32), (32, 32)), ((20, 24, 70), (20, 70)), ((40, 36, 130), (44, 150))])
+def test_untilted_poses_take_the_flat_tile_kernels(PM, orc, shape, ndet):
+    """alpha = beta = 0 with arbitrary phi, (tx, ty, tz) and centre-of-rotation shifts: the flat tile kernels
+    (uniform x,y weights, hoisted z-lerp) against the oracle and against the general tile kernels."""
+    rng = np.random.default_rng(12)
+    n_proj = 5
+    cor = np.zeros((n_proj, 3))
+    cor[:, 0] = rng.uniform(-1.5, 1.5, n_proj)
+    geo, og = geo_pair(n_proj, None, ndet=ndet, shape=shape, cor_shift=cor)
+    phi = np.array([0.0, 0.37, np.pi / 2, 2.2, np.pi])
+    xyz = rng.uniform(-3, 3, (n_proj, 3))
+    xyz[0] = 0.0                                              # fully degenerate first pose: integer coordinates
+    x = rng.uniform(0, 1, shape).astype(np.float32)
+    y = rng.standard_normal(n_proj * ndet[0] * ndet[1]).astype(np.float32)
+    want = orc.forward(og, x, phi=phi, xyz_shift=xyz).ravel()
+    wantT = orc.adjoint(og, y, phi=phi, xyz_shift=xyz)
+    res = {}
+    for flat in (1, 0):
+        P = PM(geo)
+        P.backend.ctx.set_option("tile_flat", flat)
+        P.backend.ctx.profile_reset()
+        P.backend.ctx.profile_enable(True)
+        A = P.projection_matrix(phi=phi, xyz_shift=xyz)
+        res[flat] = (A.dot(x.ravel()), A.T.dot(y))
+        P.backend.ctx.profile_enable(False)
+        used_flat = P.backend.ctx.profile_get("k_fwd_tile_flat")[0] + P.backend.ctx.profile_get("k_adj_tile_flat")[0]
+        assert (used_flat == 2) == bool(flat)
+        assert rel_max(res[flat][0], want) < TOL and rel_max(res[flat][1], wantT) < TOL
+    assert rel_max(res[1][0], res[0][0]) < 2e-6 and rel_max(res[1][1], res[0][1]) < 2e-6
+
+
+def test_mixed_tilted_and_untilted_call(PM, orc):
+    rng = np.random.default_rng(13)
+    geo, og = geo_pair(4, 24)
+    phi = np.array([0.3, 1.0, 1.9, 2.7])
+    alpha = np.array([0.0, 0.02, 0.0, -0.01])
+    beta = np.array([0.0, 0.0, 0.0, 0.015])
+    xyz = rng.uniform(-2, 2, (4, 3))
+    x = rng.uniform(0, 1, 24 ** 3).astype(np.float32)
+    y = rng.standard_normal(4 * 576).astype(np.float32)
+    A = PM(geo).projection_matrix(alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz)
+    assert rel_max(A.dot(x), orc.forward(og, x, alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz).ravel()) < TOL
+    assert rel_max(A.T.dot(y), orc.adjoint(og, y, alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz)) < TOL

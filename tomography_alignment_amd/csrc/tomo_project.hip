@@ -282,7 +282,8 @@ struct AdjC {
     double p0[3], u[3], w[3], d[3];
     double minv[3][3];   // (ix, iz, j) = minv * (p - p0)
     int64_t fp0[3], fu[3], fw[3], fd[3];   // the same lattice in 32.32 fixed point (index space)
-    int32_t n, pad_;
+    int32_t n;
+    int32_t slot;        // row block of the sinogram this projection reads / writes (its index in the caller's pose list)
 };
 
 __global__ __launch_bounds__(256) void k_absmax(const float *__restrict__ v, int64_t n, unsigned *__restrict__ out)
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
                     for (int izb = iz_first; izb <= iz_last; izb += 64) {
                         const int iz = izb + lane;
                         const bool lane_ok = iz <= iz_last;
-                        float *pr = proj + (size_t)ip * n_det + (size_t)ix * g.ndz + iz;
+                        float *pr = proj + (size_t)c.slot * n_det + (size_t)ix * g.ndz + iz;
                         int64_t px = rb0 + (int64_t)izb * c.fw[0] + lw0;
                         int64_t py = rb1 + (int64_t)izb * c.fw[1] + lw1;
                         int64_t pz = rb2 + (int64_t)izb * c.fw[2] + lw2;
@@ -485,6 +486,169 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
         if (FWD) break;
         __syncthreads();
         // flush this batch: interior of the image is exclusively ours, the +1 faces are shared => global atomics
+        for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) {
+            const int v = acc[e];
+            if (v != 0) {
+                acc[e] = 0;
+                const int lz = e % ALZ, t2 = e / ALZ, ly = t2 % ALY, lx = t2 / ALY;
+                const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
+                if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz)
+                    atomicAdd(&vol[((size_t)gx * g.ny + gy) * g.nz + gz], (float)v * inv_scale);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// "flat" tile kernels for UNTILTED lattices (alpha = beta = 0, detector-z pitch 1; any phi, translation, COR shift):
+//   fw = (0, 0, 1), fu_z = fd_z = 0  =>  x,y of a sample depend on (ix, j) only, z on iz only.
+// Then for one detector row the cell (lx, ly), the x/y weights and the LDS address are the same in all 64 lanes, and
+// every lane sees the same z fraction.  So: lane l is pinned to LDS plane l; one lane per SAMPLE precomputes
+// (address, own, w00, w01, w10, w11) once per row; the sample loop broadcasts those 6 words with v_readlane and does
+// 2 ds_read2_b32 + 4 FMA (forward) or 4 mul + 4 cvt + 4 ds_add_u32 (adjoint) per lane; the z-lerp is applied once per
+// row (forward: to the accumulated plane sums S_l, S_{l+1}; adjoint: to the sinogram row before the loop).
+// Same sums as k_tile, regrouped: ~11 VALU per sample instead of ~32.
+// ------------------------------------------------------------------------------------------------
+template <bool FWD>
+__global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
+                                                              float *__restrict__ vol, TomoGeomC g, const unsigned *__restrict__ absmax_bits,
+                                                              float weight_bound)
+{
+    __shared__ int acc[ALX * ALY * ALZ];
+    const float *img = (const float *)acc;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int z0 = -1 + (int)blockIdx.x * ATZ, y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + (int)blockIdx.z * ATX;
+    float scale = 1.f, inv_scale = 1.f;
+    if (FWD) {
+        bool any_nz = false;
+        for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) {
+            const int lz = e % ALZ, t2 = e / ALZ, ly = t2 % ALY, lx = t2 / ALY;
+            const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
+            float v = 0.f;
+            if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz) v = vol[((size_t)gx * g.ny + gy) * g.nz + gz];
+            ((float *)acc)[e] = v;
+            any_nz |= (v != 0.f);
+        }
+        if (!__syncthreads_or(any_nz)) return;
+    } else {
+        const float ymax = __uint_as_float(*absmax_bits);
+        if (!(ymax > 0.f)) return;
+        scale = 1073741824.f / ((float)min(n_proj, ADJ_BATCH) * ymax * weight_bound);
+        inv_scale = 1.f / scale;
+        for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) acc[e] = 0;
+        __syncthreads();
+    }
+    const float bcx = (float)x0 + 0.5f * ATX, bcy = (float)y0 + 0.5f * ATY;
+    const int64_t orgx = (int64_t)x0 << 32, orgy = (int64_t)y0 << 32;
+    const size_t n_det = (size_t)g.ndx * g.ndz;
+    const float two_m32 = 2.3283064365386963e-10f;
+    const unsigned lane4 = (unsigned)min(lane, ALZ - 1) * 4u;      // lanes 61..63 alias the halo plane with zero weight
+
+    const int batch = FWD ? n_proj : ADJ_BATCH;
+    for (int ip0 = 0; ip0 < n_proj; ip0 += batch) {
+        const int ip1 = min(n_proj, ip0 + batch);
+        for (int ip = ip0; ip < ip1; ++ip) {
+            const AdjC &c = pcs[ip];
+            // z: ray iz sits in plane lz = floor(p0z) + iz - z0 with the same fraction for every ray
+            const int p0z_i = (int)(c.fp0[2] >> 32);
+            const float wcz = (float)(unsigned)c.fp0[2] * two_m32, wfz = 1.f - wcz;
+            const int izoff = z0 - p0z_i;                              // iz = lane + izoff
+            if (izoff + ATZ <= 0 || izoff >= g.ndz) continue;          // no ray of this projection floors into the tile's z range
+            // detector rows crossing the tile's x,y footprint (2-D: a linear functional over a rectangle)
+            const float qx = bcx - (float)c.p0[0], qy = bcy - (float)c.p0[1];
+            const float m00 = (float)c.minv[0][0], m01 = (float)c.minv[0][1];
+            const float ixc = m00 * qx + m01 * qy;
+            const float ixr = fabsf(m00) * (0.5f * ATX) + fabsf(m01) * (0.5f * ATY) + 2e-2f;
+            const int ix_lo = max(0, (int)ceilf(fmaxf(ixc - ixr, -1.f)));
+            const int ix_hi = min(g.ndx - 1, (int)floorf(fminf(ixc + ixr, (float)g.ndx)));
+            if (ix_lo > ix_hi) continue;
+            const int n_rows_w = (ix_hi - ix_lo - wv) >= 0 ? (ix_hi - ix_lo - wv) / ADJ_WAVES + 1 : 0;
+            const float fp0x = (float)c.p0[0] - (float)x0, fp0y = (float)c.p0[1] - (float)y0;
+            const float fux = (float)c.u[0], fuy = (float)c.u[1], fdx = (float)c.d[0], fdy = (float)c.d[1];
+            const int iz = izoff + lane;
+            const bool ray_ok = lane < ATZ && iz >= 0 && iz < g.ndz;   // the ray this lane owns (plane ATZ is halo only)
+
+            for (int r0 = 0; r0 < n_rows_w; r0 += 64) {
+                int v_jlo = 0, v_jhi = 0;
+                {
+                    const int rix = ix_lo + wv + ADJ_WAVES * (r0 + lane);
+                    const float frix = (float)rix;
+                    float t0 = 0.f, t1 = (float)(c.n - 1);
+                    {
+                        const float cb = fp0x + frix * fux;
+                        if (fdx != 0.f) {
+                            const float inv = 1.f / fdx, ta = (-2e-2f - cb) * inv, tb = ((float)ATX + 2e-2f - cb) * inv;
+                            t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
+                        } else if (cb < -2e-2f || cb >= (float)ATX + 2e-2f) { t0 = 1.f; t1 = 0.f; }
+                    }
+                    {
+                        const float cb = fp0y + frix * fuy;
+                        if (fdy != 0.f) {
+                            const float inv = 1.f / fdy, ta = (-2e-2f - cb) * inv, tb = ((float)ATY + 2e-2f - cb) * inv;
+                            t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
+                        } else if (cb < -2e-2f || cb >= (float)ATY + 2e-2f) { t0 = 1.f; t1 = 0.f; }
+                    }
+                    if (rix <= ix_hi && t0 <= t1) {
+                        v_jlo = max(0, (int)ceilf(t0));
+                        v_jhi = min(c.n, (int)floorf(t1) + 1);
+                    }
+                }
+                const int r_end = min(64, n_rows_w - r0);
+                for (int r = 0; r < r_end; ++r) {
+                    const int jlo = __builtin_amdgcn_readlane(v_jlo, r), jhi = __builtin_amdgcn_readlane(v_jhi, r);
+                    if (jhi <= jlo) continue;
+                    const int ix = ix_lo + wv + ADJ_WAVES * (r0 + r);
+                    float *pr = proj + (size_t)c.slot * n_det + (size_t)ix * g.ndz + iz;
+                    const int64_t rbx = c.fp0[0] + (int64_t)ix * c.fu[0] - orgx, rby = c.fp0[1] + (int64_t)ix * c.fu[1] - orgy;
+                    float S = 0.f;            // forward: sum over samples of the x,y-interpolated plane `lane`
+                    float yt = 0.f;           // adjoint: what this row adds to plane `lane` per unit x,y weight (fixed-point scaled)
+                    if (!FWD) {
+                        const float yv = ray_ok ? *pr : 0.f;
+                        const float ym1 = __shfl_up(yv, 1, 64);        // ray of plane lane-1 (lane 0: belongs to the tile below)
+                        yt = (wfz * yv + (lane > 0 ? wcz * ym1 : 0.f)) * scale;
+                    }
+                    for (int jc = jlo; jc < jhi; jc += 64) {
+                        // one lane per SAMPLE: cell, ownership in x,y and the four x,y weights of sample jc + lane
+                        const int64_t px = rbx + (int64_t)(jc + lane) * c.fd[0], py = rby + (int64_t)(jc + lane) * c.fd[1];
+                        const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32);
+                        const bool own = (lx | ly) < (unsigned)ATX && jc + lane < jhi;
+                        const unsigned t_e = own ? (__umul24(lx, ALY * ALZ) + __umul24(ly, ALZ)) * 4u : 0xffffffffu;
+                        const float wx = (float)(unsigned)px * two_m32, wy = (float)(unsigned)py * two_m32;
+                        const float t_w11 = wx * wy, t_w10 = wx - t_w11, t_w01 = wy - t_w11, t_w00 = 1.f - wx - t_w01;
+                        const int cnt = min(64, jhi - jc);
+                        for (int jj = 0; jj < cnt; ++jj) {
+                            const unsigned e4 = (unsigned)__builtin_amdgcn_readlane((int)t_e, jj);
+                            if (e4 == 0xffffffffu) continue;                       // sample not in this tile's x,y cells (scalar branch)
+                            const float w00 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t_w00), jj));
+                            const float w01 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t_w01), jj));
+                            const float w10 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t_w10), jj));
+                            const float w11 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t_w11), jj));
+                            if (FWD) {
+                                const float *q = (const float *)((const char *)img + (e4 + lane4));
+                                S = fmaf(w00, q[0], S);
+                                S = fmaf(w01, q[ALZ], S);
+                                S = fmaf(w10, q[ALY * ALZ], S);
+                                S = fmaf(w11, q[ALY * ALZ + ALZ], S);
+                            } else {
+                                int *q = (int *)((char *)acc + (e4 + lane4));
+                                atomicAdd(q, cvt_round_i32(yt * w00));
+                                atomicAdd(q + ALZ, cvt_round_i32(yt * w01));
+                                atomicAdd(q + ALY * ALZ, cvt_round_i32(yt * w10));
+                                atomicAdd(q + ALY * ALZ + ALZ, cvt_round_i32(yt * w11));
+                            }
+                        }
+                    }
+                    if (FWD) {
+                        const float Sp1 = __shfl_down(S, 1, 64);                   // plane lane+1
+                        if (ray_ok) atomicAdd(pr, wfz * S + wcz * Sp1);
+                    }
+                }
+            }
+        }
+        if (FWD) break;
+        __syncthreads();
         for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) {
             const int v = acc[e];
             if (v != 0) {
@@ -689,31 +853,28 @@ static bool invert3(const double m[3][3], double inv[3][3], double *det_out)
     return true;
 }
 
-// Per-projection constants of the tile kernels, staged to the device.  Returns false (and stages nothing) when
-// some projection's detector-z axis does not map mostly onto volume z (tilt beyond ~45 deg) or its lattice is
-// singular: those calls take the ray-driven / atomic kernels instead.
-static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, bool *all_ok, double *weight_bound)
+// Per-projection constants of the tile kernels, staged to the device as [flat projections..., general projections...].
+// all_ok = false (nothing staged) when some projection's detector-z axis does not map mostly onto volume z (tilt beyond
+// ~45 deg) or its lattice is singular / out of fixed-point range: those calls take the ray-driven / atomic kernels.
+static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, bool *all_ok, double *weight_bound, int *n_flat)
 {
     const TomoGeomC &g = ctx->g;
     *all_ok = false;
     *weight_bound = 2.0;
+    *n_flat = 0;
     TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int rc = tomo_ensure_stage(ctx, sizeof(AdjC) * (size_t)std::max(n_proj, 1));
     if (rc) return rc;
-    AdjC *h = (AdjC *)ctx->h_stage;
+    std::vector<AdjC> flat, gen;
     for (int i = 0; i < n_proj; ++i) {
         ProjC pc;
         tomo_make_projc(g, h_poses + (size_t)i * TOMO_POSE_STRIDE, pc, nullptr);
-        AdjC &a = h[i];
+        AdjC a;
         double m[3][3], det = 0.0;
+        bool fits = true;
         for (int r = 0; r < 3; ++r) {
             a.p0[r] = pc.p0[r]; a.u[r] = pc.u[r]; a.w[r] = pc.w[r]; a.d[r] = pc.d[r];
             m[r][0] = pc.u[r]; m[r][1] = pc.w[r]; m[r][2] = pc.d[r];
-        }
-        a.n = pc.n;
-        a.pad_ = 0;
-        bool fits = true;
-        for (int r = 0; r < 3; ++r) {
             const double lim = 1073741824.0;     // |coordinate| < 2^30 voxels
             fits = fits && fabs(pc.p0[r]) < lim && fabs(pc.u[r]) * g.ndx < lim && fabs(pc.w[r]) * g.ndz < lim && fabs(pc.d[r]) * pc.n < lim;
             a.fp0[r] = llround(pc.p0[r] * 4294967296.0);
@@ -721,13 +882,23 @@ static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, b
             a.fw[r] = llround(pc.w[r] * 4294967296.0);
             a.fd[r] = llround(pc.d[r] * 4294967296.0);
         }
+        a.n = pc.n;
+        a.slot = i;
         if (!fits) return TOMO_OK;
         if (!invert3(m, a.minv, &det)) return TOMO_OK;
         if (!(pc.w[2] > 0.7 * sqrt(pc.w[0] * pc.w[0] + pc.w[1] * pc.w[1] + pc.w[2] * pc.w[2]))) return TOMO_OK;
         // samples per unit volume = 1/|det[u w d]|; the tent weights a voxel collects from one projection sum to about
         // that density (exactly 1 for an axis-aligned unit lattice); x2 head-room for the fixed-point image
         *weight_bound = std::max(*weight_bound, 2.0 / fabs(det));
+        const bool untilted = a.fw[0] == 0 && a.fw[1] == 0 && a.fw[2] == ((int64_t)1 << 32) && a.fu[2] == 0 && a.fd[2] == 0 &&
+                              ctx->tile_flat != 0;
+        (untilted ? flat : gen).push_back(a);
     }
+    AdjC *h = (AdjC *)ctx->h_stage;
+    size_t k = 0;
+    for (const AdjC &a : flat) h[k++] = a;
+    for (const AdjC &a : gen) h[k++] = a;
+    *n_flat = (int)flat.size();
     if (n_proj) TOMO_HIP(ctx, hipMemcpyAsync(ctx->d_stage, h, sizeof(AdjC) * (size_t)n_proj, hipMemcpyHostToDevice, ctx->stream));
     *all_ok = true;
     return TOMO_OK;
@@ -747,14 +918,20 @@ extern "C" int tomo_forward(tomo_ctx *ctx, const double *h_poses, int n_proj, co
         const dim3 grid = tile_grid(g);
         bool ok = false;
         double wb = 2.0;
+        int n_flat = 0;
         if (grid.y <= 65535 && grid.z <= 65535) {
-            rc = stage_tile_consts(ctx, h_poses, n_proj, &ok, &wb);
+            rc = stage_tile_consts(ctx, h_poses, n_proj, &ok, &wb, &n_flat);
             if (rc) return rc;
         }
         if (ok) {
+            const AdjC *d_c = (const AdjC *)ctx->d_stage;
             TOMO_HIP(ctx, hipMemsetAsync(d_proj, 0, n_det * (size_t)n_proj * sizeof(float), ctx->stream));
-            TOMO_LAUNCH(ctx, "k_fwd_tile", k_tile<true>, grid, dim3(ADJ_WAVES * 64), 0, (const AdjC *)ctx->d_stage, n_proj, d_proj,
-                        (float *)d_vol, g, (const unsigned *)nullptr, 1.f);
+            if (n_flat > 0)
+                TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_tile_flat<true>, grid, dim3(ADJ_WAVES * 64), 0, d_c, n_flat, d_proj, (float *)d_vol, g,
+                            (const unsigned *)nullptr, 1.f);
+            if (n_proj > n_flat)
+                TOMO_LAUNCH(ctx, "k_fwd_tile", k_tile<true>, grid, dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, d_proj, (float *)d_vol,
+                            g, (const unsigned *)nullptr, 1.f);
             return TOMO_OK;
         }
     }
@@ -801,8 +978,9 @@ extern "C" int tomo_adjoint(tomo_ctx *ctx, const double *h_poses, int n_proj, co
     const dim3 grid = tile_grid(g);
     bool ok = false;
     double weight_bound = 2.0;
+    int n_flat = 0;
     if (ctx->adj_variant != 1 && n_proj > 0 && grid.y <= 65535 && grid.z <= 65535) {
-        int rc = stage_tile_consts(ctx, h_poses, n_proj, &ok, &weight_bound);
+        int rc = stage_tile_consts(ctx, h_poses, n_proj, &ok, &weight_bound, &n_flat);
         if (rc) return rc;
     }
     if (!ok) return adjoint_atomic(ctx, h_poses, n_proj, d_proj, d_vol, accumulate);
@@ -813,8 +991,13 @@ extern "C" int tomo_adjoint(tomo_ctx *ctx, const double *h_poses, int n_proj, co
     TOMO_HIP(ctx, hipMemsetAsync(d_absmax, 0, sizeof(unsigned), ctx->stream));
     const int64_t n_y = (int64_t)n_det * n_proj;
     TOMO_LAUNCH(ctx, "k_absmax", k_absmax, dim3((unsigned)std::min<int64_t>((n_y + 255) / 256, 2048)), dim3(256), 0, d_proj, n_y, d_absmax);
-    TOMO_LAUNCH(ctx, "k_adj_tile", k_tile<false>, grid, dim3(ADJ_WAVES * 64), 0, (const AdjC *)ctx->d_stage, n_proj, (float *)d_proj, d_vol, g,
-                (const unsigned *)d_absmax, (float)weight_bound);
+    const AdjC *d_c = (const AdjC *)ctx->d_stage;
+    if (n_flat > 0)
+        TOMO_LAUNCH(ctx, "k_adj_tile_flat", k_tile_flat<false>, grid, dim3(ADJ_WAVES * 64), 0, d_c, n_flat, (float *)d_proj, d_vol, g,
+                    (const unsigned *)d_absmax, (float)weight_bound);
+    if (n_proj > n_flat)
+        TOMO_LAUNCH(ctx, "k_adj_tile", k_tile<false>, grid, dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, (float *)d_proj, d_vol, g,
+                    (const unsigned *)d_absmax, (float)weight_bound);
     return TOMO_OK;
 }
 
