@@ -12,6 +12,15 @@ import json
 import os
 
 
+ALIAS = {"k_tile_flat<true>": "k_fwd_tile_flat", "k_tile_flat<false>": "k_adj_tile_flat", "k_tile<true>": "k_fwd_tile",
+         "k_tile<false>": "k_adj_tile", "k_proj_grad<true>": "k_cost_grad", "k_proj_grad<false>": "k_proj_grad"}
+
+
+def short(name):
+    k = name.split("(")[0].replace("void ", "")
+    return ALIAS.get(k, k)
+
+
 def find(d, pat):
     m = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
     return m[0] if m else None
@@ -24,8 +33,7 @@ def pmc(d, name):
     path = find(d, "*counter_collection.csv")
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == name:
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            out.setdefault(k, []).append(float(r["Counter_Value"]))
+            out.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
     return out
 
 
@@ -46,8 +54,19 @@ def main():
              "## `rocprofv3 --kernel-trace --stats -- python3 bench.py ...`", "",
              "| kernel | calls | avg ms | total ms | % |", "|---|---|---|---|---|"]
     for r in rows:
-        lines.append("| `%s` | %s | %.3f | %.1f | %s |" % (r["Name"].split("(")[0].replace("void ", ""), r["Calls"], float(r["AverageNs"]) / 1e6,
+        lines.append("| `%s` | %s | %.3f | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e6,
                                                           float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+    # per-dispatch durations: the stats above average over EVERY dispatch of the process (set-up launches on other inputs
+    # included); bench.py's `kernels` / `roofline.avg_launch_ms` average the timed steps only = the last dispatches below
+    trace = find(a.stats_dir, "*kernel_trace.csv")
+    if trace:
+        per = {}
+        for r in csv.DictReader(open(trace)):
+            per.setdefault(short(r["Kernel_Name"]), []).append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6)
+        lines += ["", "## per-dispatch durations (ms, in launch order) of the projector kernels", ""]
+        for k, v in per.items():
+            if k.startswith(("k_fwd", "k_adj", "k_cost_grad")):
+                lines.append("* `%s`: %s" % (k, ", ".join("%.1f" % x for x in v)))
     traffic = {}
     if fetch or write:
         lines += ["", "## PMC passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, separate runs; per launch, max over launches)", "",
