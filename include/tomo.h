@@ -83,7 +83,10 @@ TOMO_API int tomo_memcpy_d2h(tomo_ctx *ctx, void *h_dst, const void *d_src, size
 TOMO_API int tomo_memcpy_d2d(tomo_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 TOMO_API int tomo_memset0(tomo_ctx *ctx, void *d_ptr, size_t bytes);
 TOMO_API int tomo_sync(tomo_ctx *ctx);
-/* Integer tuning knobs ("fwd_variant", "adj_variant", ...); unknown keys are TOMO_ERR_ARG. */
+/* Integer knobs; unknown keys are TOMO_ERR_ARG.
+ *   "fwd_variant" 1 ray-driven (plain), 2 ray-driven (SGPR block base), 3 LDS tile kernels (default)
+ *   "adj_variant" 1 global float atomics, 2 LDS tile kernels with fixed-point accumulation (default)
+ *   "tile_flat"   1 (default): untilted projections (alpha = beta = 0, detector-z pitch 1) take the flat tile kernels */
 TOMO_API int tomo_set_option(tomo_ctx *ctx, const char *key, int value);
 
 /* Geometry: replaces passing a `Geometry` object to utilities/ray_voxel_utilities.py:53,113. */

@@ -133,7 +133,6 @@ extern "C" int tomo_set_option(tomo_ctx *ctx, const char *key, int value)
     if (!ctx || !key) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
     if (!strcmp(key, "fwd_variant")) ctx->fwd_variant = value;
     else if (!strcmp(key, "adj_variant")) ctx->adj_variant = value;
-    else if (!strcmp(key, "adj_batch")) ctx->adj_batch = value;
     else if (!strcmp(key, "tile_flat")) ctx->tile_flat = value;
     else return tomo_fail(ctx, TOMO_ERR_ARG, std::string("unknown option ") + key);
     return TOMO_OK;
