@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--perturbed", action="store_true", help="alpha,beta ~ U(+-1 deg), tx,tz ~ U(+-2 px) (default_rng(0))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-align", action="store_true", help="skip the alignment-gradient evals/s side measurement (config 5)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="N=1 only: run the multi-GPU code path (sharded solver, x-slab pipelined all-reduce) on a 1-rank RCCL communicator")
     ap.add_argument("--fwd-variant", type=int, default=None)
     ap.add_argument("--adj-variant", type=int, default=None)
     args = ap.parse_args()
@@ -61,6 +63,10 @@ def main():
     N, n_proj = args.size, args.angles
     comm = RcclComm.from_env()
     ctx = comm.ctx
+    if args.force_sharded and world == 1:
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        comm = RcclComm(ctx, 0, 1, RcclComm.unique_id(ctx.lib))
+        comm.force_pipeline = True
     if args.fwd_variant is not None:
         ctx.set_option("fwd_variant", args.fwd_variant)
     if args.adj_variant is not None:
@@ -85,7 +91,7 @@ def main():
     poses = _lib.poses_array(phi[my_rows], alpha[my_rows], beta[my_rows], xyz[my_rows], np.zeros(3))
     d_b = be.forward(poses, d_true, be.empty(my_rows.size * N * N))
     opts = {"_backend": be}
-    if world > 1:
+    if world > 1 or args.force_sharded:
         solver = sirt_mpi.SIRT(comm, geo, d_b, angles, xyz, opts)
     else:
         solver = sirt_mod.SIRT(geo, d_b, angles, xyz, opts)
@@ -182,7 +188,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(be, d_true, N, n_proj, phi)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_sharded:
         comm.close()
 
 

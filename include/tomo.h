@@ -108,6 +108,14 @@ TOMO_API int tomo_forward(tomo_ctx *ctx, const double *h_poses, int n_proj, cons
 TOMO_API int tomo_adjoint(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_proj, float *d_vol,
                  int accumulate);
 
+/* x-slab form of tomo_adjoint for pipelining the all-reduce of recon/sirt_mpi.py:103 with the back-projection:
+ *   the volume is x-major, so the tile columns [xt0, xt1) (width *tile_width voxels, *n_xtiles of them) finalise the
+ *   CONTIGUOUS voxel range x in [tile_width*xt0 - 1, tile_width*xt1 - 1) (clipped to [0, nx); the last column runs to nx)
+ *   once the columns below it are done.  Adds into d_vol (zero it first).  TOMO_ERR_UNSUPPORTED for poses the tile
+ *   kernels decline -- use tomo_adjoint then. */
+TOMO_API int tomo_adjoint_xslab_info(tomo_ctx *ctx, int *n_xtiles, int *tile_width);
+TOMO_API int tomo_adjoint_xslab(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_proj, float *d_vol, int xt0, int xt1);
+
 /* tomo_backproject_voxel: the voxel-driven bilinear back-projector src/back_projection.f90:1-34
  *   (voxel_rigid_transformation + voxel_back_bilinear, src/external_back_projection.f90:1-68):
  *   x' = Ry(beta)(Rx(alpha) Rz(phi) c + t), bilinear gather at (x'_x - origin_x, x'_z - origin_z).
@@ -177,6 +185,10 @@ TOMO_API int tomo_comm_get_unique_id(void *h_id128);
 TOMO_API int tomo_comm_init(tomo_ctx *ctx, const void *h_id128, int n_ranks, int rank);
 TOMO_API int tomo_comm_destroy(tomo_ctx *ctx);
 TOMO_API int tomo_allreduce_sum_f32(tomo_ctx *ctx, float *d_buf, int64_t n);     /* in place, on ctx stream */
+/* asynchronous form: the all-reduce runs on the ctx's communication stream after everything queued so far on the compute
+ * stream; tomo_comm_join makes the compute stream wait for every asynchronous all-reduce issued before it. */
+TOMO_API int tomo_allreduce_sum_f32_async(tomo_ctx *ctx, float *d_buf, int64_t n);
+TOMO_API int tomo_comm_join(tomo_ctx *ctx);
 TOMO_API int tomo_allreduce_sum_f64_host(tomo_ctx *ctx, double *h_vals, int n);  /* small host scalars */
 TOMO_API int tomo_allreduce_max_f64_host(tomo_ctx *ctx, double *h_vals, int n);
 

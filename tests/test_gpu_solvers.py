@@ -171,3 +171,32 @@ def test_batched_alignment_gpu(shepp32):
     res = alignment.align_projections(HipBackend(geom(n, N)), shepp32, b, phi, letters="xzab",
                                       bounds=((-3., 3.), (-3., 3.), (-0.02, 0.02), (-0.02, 0.02)))
     assert np.allclose(res["x"], true, atol=1e-4) and res["n_launch"] < res["n_eval"]
+
+
+def test_pipelined_allreduce_path_matches_plain(shepp32):
+    """The x-slab back-projection + asynchronous all-reduce sequence of the sharded SIRT, driven through a real
+    1-rank RCCL communicator (same streams / events as N ranks), against the plain sequence."""
+    import os
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    from tomography_alignment_amd import _lib
+    from tomography_alignment_amd.backend import HipBackend
+    from tomography_alignment_amd.comm import RcclComm
+    from tomography_alignment_amd.recon import sirt_mpi
+    g = golden("g5_sirt")
+    N = 32
+    geo = geom(16, N)
+    angles = np.array([g["phi"], g["alpha"], g["beta"]]).T
+    untilted = np.array([g["phi"], 0 * g["alpha"], 0 * g["beta"]]).T
+    ctx = _lib.Context(0)
+    comm = RcclComm(ctx, 0, 1, RcclComm.unique_id(ctx.lib))
+    for ang in (angles, untilted):
+        res = {}
+        for force in (False, True):
+            comm.force_pipeline = force
+            s = sirt_mpi.SIRT(comm, geo, g["b"].copy(), ang, g["xyz"], options={"_backend": HipBackend(geo, ctx=ctx)})
+            s.n_pipeline_slabs = 3
+            res[force] = s.run_main_iteration(niter=6)
+        assert rel_max(res[True][0], res[False][0]) < 2e-6 and np.allclose(res[True][1], res[False][1], rtol=1e-6)
+    be = HipBackend(geo, ctx=ctx)
+    assert be.xslab_info() == (3, 16)
+    comm.close()

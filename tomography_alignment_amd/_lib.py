@@ -50,6 +50,8 @@ SIGNATURES = {
     "tomo_set_geometry": (ctypes.c_int, [_c_vp, ctypes.POINTER(TomoGeom)]),
     "tomo_forward": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp]),
     "tomo_adjoint": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp, ctypes.c_int]),
+    "tomo_adjoint_xslab_info": (ctypes.c_int, [_c_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "tomo_adjoint_xslab": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int]),
     "tomo_backproject_voxel": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp]),
     "tomo_proj_grad": (ctypes.c_int, [_c_vp, _c_dp, _c_vp, _c_vp, _c_vp, ctypes.c_int]),
     "tomo_cost_grad": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp, _c_dp, _c_dp, _c_vp]),
@@ -71,6 +73,8 @@ SIGNATURES = {
     "tomo_comm_init": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int]),
     "tomo_comm_destroy": (ctypes.c_int, [_c_vp]),
     "tomo_allreduce_sum_f32": (ctypes.c_int, [_c_vp, _c_vp, _c_i64]),
+    "tomo_allreduce_sum_f32_async": (ctypes.c_int, [_c_vp, _c_vp, _c_i64]),
+    "tomo_comm_join": (ctypes.c_int, [_c_vp]),
     "tomo_allreduce_sum_f64_host": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int]),
     "tomo_allreduce_max_f64_host": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int]),
     "tomo_timer_start": (ctypes.c_int, [_c_vp]),

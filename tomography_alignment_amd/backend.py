@@ -69,6 +69,19 @@ class HipBackend(object):
         self.ctx.check(self.lib.tomo_adjoint(self.ctx.handle, _lib.dptr(poses), n, proj.ptr, out.ptr, 1 if accumulate else 0))
         return out
 
+    def xslab_info(self):
+        """(number of x tile columns, their width in voxels) of the tile adjoint."""
+        self._geom()
+        n, w = ctypes.c_int(0), ctypes.c_int(0)
+        self.ctx.check(self.lib.tomo_adjoint_xslab_info(self.ctx.handle, ctypes.byref(n), ctypes.byref(w)))
+        return n.value, w.value
+
+    def adjoint_xslab(self, poses, proj, out, xt0, xt1):
+        """A^T y restricted to the x tile columns [xt0, xt1); ADDS into `out` (zero it first).  Raises TomoError for poses
+        the tile kernels decline."""
+        self._geom()
+        self.ctx.check(self.lib.tomo_adjoint_xslab(self.ctx.handle, _lib.dptr(poses), poses.shape[0], proj.ptr, out.ptr, int(xt0), int(xt1)))
+
     def backproject_voxel(self, poses, det, out):
         self._geom()
         n = poses.shape[0]

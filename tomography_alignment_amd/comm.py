@@ -127,6 +127,15 @@ class RcclComm(object):
         self.ctx.check(self.ctx.lib.tomo_allreduce_sum_f32(self.ctx.handle, buf.ptr, buf.size))
         return buf
 
+    def allreduce_sum_async(self, buf):
+        """Start an in-place sum of `buf` on the communication stream (after everything queued on the compute stream);
+        `join()` makes the compute stream wait for all of them."""
+        self.ctx.check(self.ctx.lib.tomo_allreduce_sum_f32_async(self.ctx.handle, buf.ptr, buf.size))
+        return buf
+
+    def join(self):
+        self.ctx.check(self.ctx.lib.tomo_comm_join(self.ctx.handle))
+
     def allreduce_scalar(self, v):
         a = np.array([v], np.float64)
         self.ctx.check(self.ctx.lib.tomo_allreduce_sum_f64_host(self.ctx.handle, _lib.dptr(a), 1))

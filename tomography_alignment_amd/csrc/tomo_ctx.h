@@ -49,6 +49,9 @@ struct tomo_ctx {
     std::vector<hipEvent_t> ev_pool;
     // comm
     ncclComm_t comm = nullptr;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_compute = nullptr, ev_comm = nullptr;
+    bool comm_pending = false;
     int n_ranks = 1, rank = 0;
     std::string err;
 };

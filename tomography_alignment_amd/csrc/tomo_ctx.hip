@@ -50,7 +50,11 @@ extern "C" int tomo_ctx_destroy(tomo_ctx *c)
     if (!c) return TOMO_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm) ncclCommDestroy(c->comm);
+    if (c->ev_compute) (void)hipEventDestroy(c->ev_compute);
+    if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     for (auto &p : c->pending) { c->ev_pool.push_back(p.e0); c->ev_pool.push_back(p.e1); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->d_volpad) (void)hipFree(c->d_volpad);
@@ -557,6 +561,7 @@ extern "C" int tomo_comm_destroy(tomo_ctx *ctx)
 {
     if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
     if (ctx->comm) {
+        if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
         (void)hipStreamSynchronize(ctx->stream);
         ncclCommDestroy(ctx->comm);
         ctx->comm = nullptr;
@@ -574,6 +579,34 @@ extern "C" int tomo_allreduce_sum_f32(tomo_ctx *ctx, float *d_buf, int64_t n)
     ncclResult_t r = ncclAllReduce(d_buf, d_buf, (size_t)n, ncclFloat32, ncclSum, ctx->comm, ctx->stream);
     tomo_prof_end(ctx);
     if (r != ncclSuccess) return tomo_fail(ctx, TOMO_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    return TOMO_OK;
+}
+
+extern "C" int tomo_allreduce_sum_f32_async(tomo_ctx *ctx, float *d_buf, int64_t n)
+{
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    if (!ctx->comm) return ctx->n_ranks == 1 ? TOMO_OK : tomo_fail(ctx, TOMO_ERR_STATE, "comm not initialised");
+    if (!ctx->comm_stream) {
+        TOMO_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+        TOMO_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_compute, hipEventDisableTiming));
+        TOMO_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming));
+    }
+    TOMO_HIP(ctx, hipEventRecord(ctx->ev_compute, ctx->stream));
+    TOMO_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_compute, 0));
+    ncclResult_t r = ncclAllReduce(d_buf, d_buf, (size_t)n, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream);
+    if (r != ncclSuccess) return tomo_fail(ctx, TOMO_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    TOMO_HIP(ctx, hipEventRecord(ctx->ev_comm, ctx->comm_stream));
+    ctx->comm_pending = true;
+    return TOMO_OK;
+}
+
+extern "C" int tomo_comm_join(tomo_ctx *ctx)
+{
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    if (ctx->comm_pending) {
+        TOMO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_comm, 0));   // events on one stream complete in order: the last covers all
+        ctx->comm_pending = false;
+    }
     return TOMO_OK;
 }
 

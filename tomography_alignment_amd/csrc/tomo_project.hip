@@ -326,13 +326,13 @@ __device__ __forceinline__ float trilerp_pairs(f32x2 p00, f32x2 p01, f32x2 p10, 
 template <bool FWD>
 __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
                                                          float *__restrict__ vol, TomoGeomC g, const unsigned *__restrict__ absmax_bits,
-                                                         float weight_bound)
+                                                         float weight_bound, int tile_x0)
 {
     __shared__ int acc[ALX * ALY * ALZ];
     const float *img = (const float *)acc;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int z0 = -1 + (int)blockIdx.x * ATZ, y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + (int)blockIdx.z * ATX;
+    const int z0 = -1 + (int)blockIdx.x * ATZ, y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + ((int)blockIdx.z + tile_x0) * ATX;
     float scale = 1.f, inv_scale = 1.f;
     if (FWD) {
         bool any_nz = false;
@@ -513,13 +513,13 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
 template <bool FWD>
 __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
                                                               float *__restrict__ vol, TomoGeomC g, const unsigned *__restrict__ absmax_bits,
-                                                              float weight_bound)
+                                                              float weight_bound, int tile_x0)
 {
     __shared__ int acc[ALX * ALY * ALZ];
     const float *img = (const float *)acc;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int z0 = -1 + (int)blockIdx.x * ATZ, y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + (int)blockIdx.z * ATX;
+    const int z0 = -1 + (int)blockIdx.x * ATZ, y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + ((int)blockIdx.z + tile_x0) * ATX;
     float scale = 1.f, inv_scale = 1.f;
     if (FWD) {
         bool any_nz = false;
@@ -928,10 +928,10 @@ extern "C" int tomo_forward(tomo_ctx *ctx, const double *h_poses, int n_proj, co
             TOMO_HIP(ctx, hipMemsetAsync(d_proj, 0, n_det * (size_t)n_proj * sizeof(float), ctx->stream));
             if (n_flat > 0)
                 TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_tile_flat<true>, grid, dim3(ADJ_WAVES * 64), 0, d_c, n_flat, d_proj, (float *)d_vol, g,
-                            (const unsigned *)nullptr, 1.f);
+                            (const unsigned *)nullptr, 1.f, 0);
             if (n_proj > n_flat)
                 TOMO_LAUNCH(ctx, "k_fwd_tile", k_tile<true>, grid, dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, d_proj, (float *)d_vol,
-                            g, (const unsigned *)nullptr, 1.f);
+                            g, (const unsigned *)nullptr, 1.f, 0);
             return TOMO_OK;
         }
     }
@@ -968,24 +968,27 @@ static int adjoint_atomic(tomo_ctx *ctx, const double *h_poses, int n_proj, cons
     return TOMO_OK;
 }
 
-extern "C" int tomo_adjoint(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_proj, float *d_vol, int accumulate)
+// tile adjoint restricted to the x tile columns [xt0, xt1): adds into d_vol (the caller zeroes it).  *done = false when the
+// poses do not qualify for the tile kernels (nothing launched).
+static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_proj, float *d_vol, int xt0, int xt1, bool *done)
 {
-    TOMO_NEED_GEOM(ctx);
-    if (!h_poses || !d_vol || !d_proj || n_proj < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_adjoint: bad args");
     const TomoGeomC &g = ctx->g;
     const size_t n_det = (size_t)g.ndx * g.ndz;
-    const size_t n_vox = (size_t)g.nx * g.ny * g.nz;
-    const dim3 grid = tile_grid(g);
+    dim3 grid = tile_grid(g);
+    *done = false;
     bool ok = false;
     double weight_bound = 2.0;
     int n_flat = 0;
-    if (ctx->adj_variant != 1 && n_proj > 0 && grid.y <= 65535 && grid.z <= 65535) {
-        int rc = stage_tile_consts(ctx, h_poses, n_proj, &ok, &weight_bound, &n_flat);
-        if (rc) return rc;
-    }
-    if (!ok) return adjoint_atomic(ctx, h_poses, n_proj, d_proj, d_vol, accumulate);
-    if (!accumulate) TOMO_HIP(ctx, hipMemsetAsync(d_vol, 0, n_vox * sizeof(float), ctx->stream));
-    int rc = tomo_ensure_red(ctx, 8);
+    if (ctx->adj_variant == 1 || n_proj <= 0 || grid.y > 65535 || grid.z > 65535) return TOMO_OK;
+    int rc = stage_tile_consts(ctx, h_poses, n_proj, &ok, &weight_bound, &n_flat);
+    if (rc) return rc;
+    if (!ok) return TOMO_OK;
+    xt0 = std::max(xt0, 0);
+    xt1 = std::min(xt1, (int)grid.z);
+    *done = true;
+    if (xt1 <= xt0) return TOMO_OK;
+    grid.z = (unsigned)(xt1 - xt0);
+    rc = tomo_ensure_red(ctx, 8);
     if (rc) return rc;
     unsigned *d_absmax = (unsigned *)(ctx->d_red + 4);
     TOMO_HIP(ctx, hipMemsetAsync(d_absmax, 0, sizeof(unsigned), ctx->stream));
@@ -994,10 +997,51 @@ extern "C" int tomo_adjoint(tomo_ctx *ctx, const double *h_poses, int n_proj, co
     const AdjC *d_c = (const AdjC *)ctx->d_stage;
     if (n_flat > 0)
         TOMO_LAUNCH(ctx, "k_adj_tile_flat", k_tile_flat<false>, grid, dim3(ADJ_WAVES * 64), 0, d_c, n_flat, (float *)d_proj, d_vol, g,
-                    (const unsigned *)d_absmax, (float)weight_bound);
+                    (const unsigned *)d_absmax, (float)weight_bound, xt0);
     if (n_proj > n_flat)
         TOMO_LAUNCH(ctx, "k_adj_tile", k_tile<false>, grid, dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, (float *)d_proj, d_vol, g,
-                    (const unsigned *)d_absmax, (float)weight_bound);
+                    (const unsigned *)d_absmax, (float)weight_bound, xt0);
+    return TOMO_OK;
+}
+
+extern "C" int tomo_adjoint(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_proj, float *d_vol, int accumulate)
+{
+    TOMO_NEED_GEOM(ctx);
+    if (!h_poses || !d_vol || !d_proj || n_proj < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_adjoint: bad args");
+    const TomoGeomC &g = ctx->g;
+    const size_t n_vox = (size_t)g.nx * g.ny * g.nz;
+    if (n_proj == 0) {
+        if (!accumulate) TOMO_HIP(ctx, hipMemsetAsync(d_vol, 0, n_vox * sizeof(float), ctx->stream));
+        return TOMO_OK;
+    }
+    // the tile kernels add into d_vol: zero it first; if the poses turn out not to qualify, the atomic path overwrites anyway
+    if (!accumulate && ctx->adj_variant != 1) TOMO_HIP(ctx, hipMemsetAsync(d_vol, 0, n_vox * sizeof(float), ctx->stream));
+    bool done = false;
+    int rc = adjoint_tiles(ctx, h_poses, n_proj, d_proj, d_vol, 0, INT_MAX, &done);
+    if (rc) return rc;
+    if (done) return TOMO_OK;
+    return adjoint_atomic(ctx, h_poses, n_proj, d_proj, d_vol, accumulate);
+}
+
+// x-slab form for pipelining the all-reduce with the back-projection (volume is x-major: the tile columns [xt0, xt1) finalise
+// the contiguous voxel range x in [ATX*xt0 - 1, ATX*xt1 - 1) clipped to [0, nx); the last column also finalises up to nx).
+extern "C" int tomo_adjoint_xslab_info(tomo_ctx *ctx, int *n_xtiles, int *tile_width)
+{
+    TOMO_NEED_GEOM(ctx);
+    if (!n_xtiles || !tile_width) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_adjoint_xslab_info: bad args");
+    *n_xtiles = (int)tile_grid(ctx->g).z;
+    *tile_width = ATX;
+    return TOMO_OK;
+}
+
+extern "C" int tomo_adjoint_xslab(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_proj, float *d_vol, int xt0, int xt1)
+{
+    TOMO_NEED_GEOM(ctx);
+    if (!h_poses || !d_vol || !d_proj || n_proj < 0 || xt0 < 0 || xt1 < xt0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_adjoint_xslab: bad args");
+    bool done = false;
+    int rc = adjoint_tiles(ctx, h_poses, n_proj, d_proj, d_vol, xt0, xt1, &done);
+    if (rc) return rc;
+    if (!done) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "tomo_adjoint_xslab: these poses do not take the tile kernels");
     return TOMO_OK;
 }
 

@@ -133,9 +133,7 @@ class SIRT(object):
         while k < niter and not stop:
             self.proj_mat.apply(self.d_rec, self.d_ax)                                  # sirt.py:59
             sumsq = be.residual_scale(self.d_b, self.d_ax, self.d_W, self.d_res)        # :60-61 (W * res) and :69
-            self.proj_mat.T.apply(self.d_res, self.d_bp)                                # :61
-            be.mul(self.d_bp, self.d_V)                                                 # :63   (sirt_mpi.py:101)
-            self._allreduce_vol(self.d_bp)                                              # sirt_mpi.py:102-103
+            self._backproject_scaled()                                                  # :61,63 ; sirt_mpi.py:98-103
             err = be.update(self.d_rec, self.d_bp, None, positivity, self.d_gt)         # :64-67,73
             convergence[k] = np.sqrt(self._allreduce_scalar(sumsq))                     # :69 ; sirt_mpi.py:110
             rms_error[k] = convergence[k] / norm_factor if self.d_gt is None else np.sqrt(err) / norm_factor
@@ -150,6 +148,13 @@ class SIRT(object):
         self.rms_error = rms_error
         self.convergence = convergence
         return k, rms_error[:k]
+
+    def _backproject_scaled(self):
+        """d_bp = V * A^T d_res, summed over the angle shards."""
+        be = self.be
+        self.proj_mat.T.apply(self.d_res, self.d_bp)                                    # sirt.py:61
+        be.mul(self.d_bp, self.d_V)                                                     # sirt.py:63 (sirt_mpi.py:101)
+        self._allreduce_vol(self.d_bp)                                                  # sirt_mpi.py:102-103
 
     def run_main_iteration(self, niter=100, make_plot=False, projections=None, positivity=False, debug=False):
         if make_plot:

@@ -57,6 +57,39 @@ class SIRT(_SIRT):
     def _is_root(self):
         return self.my_rank == 0
 
+    n_pipeline_slabs = 4      # x slabs of the back-projection whose all-reduce overlaps the next slab's kernel
+
+    def _backproject_scaled(self):
+        """recon/sirt_mpi.py:98-103 with the Allreduce pipelined: the volume is x-major, so the back-projection is done in
+        a few x slabs (tile columns); as soon as a slab is final it is scaled by V and its all-reduce starts on the
+        communication stream while the next slab is being back-projected.  Falls back to the plain sequence when the
+        backend / communicator / poses do not offer the slab form."""
+        be, comm = self.be, self.comm
+        pipelined = (self.size > 1 or getattr(comm, "force_pipeline", False)) and hasattr(be, "adjoint_xslab") and \
+            hasattr(comm, "allreduce_sum_async") and self.voxel_mask is None and self.n_pipeline_slabs > 1
+        if pipelined:
+            try:
+                n_xt, tw = be.xslab_info()
+                nx = int(self.geometry.vox_shape[0])
+                plane = be.n_vox // nx
+                cuts = np.unique(np.linspace(0, n_xt, min(self.n_pipeline_slabs, n_xt) + 1).astype(int))
+                self.d_bp.zero_()
+                for s in range(len(cuts) - 1):
+                    be.adjoint_xslab(self.proj_mat.poses, self.d_res, self.d_bp, cuts[s], cuts[s + 1])
+                    x_lo = 0 if s == 0 else min(nx, max(0, tw * int(cuts[s]) - 1))
+                    x_hi = nx if s == len(cuts) - 2 else min(nx, max(0, tw * int(cuts[s + 1]) - 1))
+                    if x_hi > x_lo:
+                        seg_bp = self.d_bp.view(x_lo * plane, (x_hi - x_lo) * plane)
+                        be.mul(seg_bp, self.d_V.view(x_lo * plane, (x_hi - x_lo) * plane))
+                        comm.allreduce_sum_async(seg_bp)
+                comm.join()
+                return
+            except Exception as e:                    # poses outside the tile kernels' domain: plain path from now on
+                if "do not take the tile kernels" not in str(e):
+                    raise
+                self.n_pipeline_slabs = 1
+        super(SIRT, self)._backproject_scaled()
+
     def _initialize(self):
         self._zero_guard = 1.e-8      # sirt_mpi.py:69-70
         self._stop_after = 1          # sirt_mpi.py:116
