@@ -121,7 +121,9 @@ def main():
                  "k_vec", "allreduce_f32"):
         n, ms = ctx.profile_get(name)
         if n:
-            kern[name] = {"launches": n, "avg_ms": ms / n}
+            # a pass over all angles may be issued as several launches (x slabs of the pipelined back-projection):
+            # ms_per_step sums them, so bytes-per-pass / ms_per_step == bytes-per-launch / avg launch time
+            kern[name] = {"launches": n, "avg_ms": ms / n, "launches_per_step": n / float(args.steps), "ms_per_step": ms / float(args.steps)}
     n_loc = my_rows.size
     n_det = N * N
     alg_fwd = n_loc * (4.0 * N ** 3 + 4.0 * n_det)               # bytes per forward launch   
@@ -130,30 +132,31 @@ def main():
     adj_name = next((k for k in ("k_adj_tile_flat", "k_adj_tile", "k_adj_v1") if k in kern), None)
     cands = []
     if fwd_name:
-        cands.append((kern[fwd_name]["avg_ms"], fwd_name, alg_fwd))
+        cands.append((kern[fwd_name]["ms_per_step"], fwd_name, alg_fwd))
     if adj_name:
-        cands.append((kern[adj_name]["avg_ms"], adj_name, alg_adj))
+        cands.append((kern[adj_name]["ms_per_step"], adj_name, alg_adj))
     roofline = None
     if cands:
-        avg_ms, name, alg = max(cands)
-        ach = alg / (avg_ms * 1e-3) / 1e9
+        step_ms, name, alg = max(cands)
+        lps = kern[name]["launches_per_step"]
+        ach = alg / (step_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                    "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(avg_ms, 3)}
+                    "algorithmic_bytes_per_launch": alg / lps, "avg_launch_ms": round(step_ms / lps, 3), "launches_per_step": lps}
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (counters cannot be
         # collected from inside the timed run; see profiles/*_rocprof_summary.md for how they were taken/corrected)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pmc.get("key") == "N%d_A%d_G%d%s" % (N, n_proj, world, "_P" if args.perturbed else "") and name in pmc["kernels"]:
-                roofline["traffic"] = pmc["kernels"][name]["hbm_bytes_per_launch"]
+                roofline["traffic"] = pmc["kernels"][name]["hbm_bytes_per_launch"] / lps
                 roofline["traffic_source"] = "profiles/pmc_traffic.json (%s)" % pmc.get("source", "")
         except (OSError, ValueError, KeyError):
             pass
     extra = {}
     if fwd_name:
-        extra["forward_alg_GBps"] = round(alg_fwd / (kern[fwd_name]["avg_ms"] * 1e-3) / 1e9, 1)
+        extra["forward_alg_GBps"] = round(alg_fwd / (kern[fwd_name]["ms_per_step"] * 1e-3) / 1e9, 1)
     if adj_name:
-        extra["backproj_alg_GBps"] = round(alg_adj / (kern[adj_name]["avg_ms"] * 1e-3) / 1e9, 1)
+        extra["backproj_alg_GBps"] = round(alg_adj / (kern[adj_name]["ms_per_step"] * 1e-3) / 1e9, 1)
 
     its = args.steps / elapsed
     out = {
