@@ -12,7 +12,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtomo_hip.so")
+LIB_PATH = os.environ.get("TOMO_HIP_LIB") or os.path.join(_HERE, "libtomo_hip.so")   # override: development builds only
 POSE_STRIDE = 7
 COMM_ID_BYTES = 128
 

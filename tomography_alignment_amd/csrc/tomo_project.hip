@@ -363,7 +363,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
     const int batch = FWD ? n_proj : ADJ_BATCH;
     for (int ip0 = 0; ip0 < n_proj; ip0 += batch) {
         const int ip1 = min(n_proj, ip0 + batch);
-        for (int ip = ip0; ip < ip1; ++ip) {
+        for (int ip = ip0 + wv; ip < ip1; ip += ADJ_WAVES) {      // one wave owns a whole (tile, projection): set-up runs once
             const AdjC &c = pcs[ip];
             // Range work is CONSERVATIVE set-up in float32 (coordinates < 2^11: float32 error < 1e-3 voxel, margins 2e-2): it
             // only has to cover the owned samples; exact ownership is decided per sample from the fixed-point position.
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
             const float izl = fmaxf(izm - izr, 0.f), izh = fminf(izm + izr, (float)(g.ndz - 1));
             if (izl > izh + 1.f) continue;
             const float izc = 0.5f * (izl + izh), hs = 0.5f * (izh - izl) + 1.f;   // lanes' iz spread about the centre line
-            const int n_rows_w = (ix_hi - ix_lo - wv) >= 0 ? (ix_hi - ix_lo - wv) / ADJ_WAVES + 1 : 0;   // this wave's rows
+            const int n_rows_w = ix_hi - ix_lo + 1;
             const float fp0[3] = {(float)c.p0[0] - (float)x0, (float)c.p0[1] - (float)y0, (float)c.p0[2] - (float)z0};   // tile-relative
             const float fu[3] = {(float)c.u[0], (float)c.u[1], (float)c.u[2]}, fw[3] = {(float)c.w[0], (float)c.w[1], (float)c.w[2]};
             const float fd[3] = {(float)c.d[0], (float)c.d[1], (float)c.d[2]};
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
                 // lanes needed for ownership in z over that range
                 int v_jlo = 0, v_jhi = 0, v_izf = 0, v_izl = -1;
                 {
-                    const int rix = ix_lo + wv + ADJ_WAVES * (r0 + lane);
+                    const int rix = ix_lo + r0 + lane;
                     const float frix = (float)rix;
                     float t0 = 0.f, t1 = (float)(c.n - 1);
 #pragma unroll
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
                     const int jlo = __builtin_amdgcn_readlane(v_jlo, r), jhi = __builtin_amdgcn_readlane(v_jhi, r);
                     if (jhi <= jlo) continue;
                     const int iz_first = __builtin_amdgcn_readlane(v_izf, r), iz_last = __builtin_amdgcn_readlane(v_izl, r);
-                    const int ix = ix_lo + wv + ADJ_WAVES * (r0 + r);
+                    const int ix = ix_lo + r0 + r;
                     // uniform part of the fixed-point position of sample jlo of this row (scalar 64-bit arithmetic)
                     const int64_t rb0 = c.fp0[0] + (int64_t)ix * c.fu[0] + (int64_t)jlo * c.fd[0] - org[0];
                     const int64_t rb1 = c.fp0[1] + (int64_t)ix * c.fu[1] + (int64_t)jlo * c.fd[1] - org[1];
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
     const int batch = FWD ? n_proj : ADJ_BATCH;
     for (int ip0 = 0; ip0 < n_proj; ip0 += batch) {
         const int ip1 = min(n_proj, ip0 + batch);
-        for (int ip = ip0; ip < ip1; ++ip) {
+        for (int ip = ip0 + wv; ip < ip1; ip += ADJ_WAVES) {      // one wave owns a whole (tile, projection): set-up runs once
             const AdjC &c = pcs[ip];
             // z: ray iz sits in plane lz = floor(p0z) + iz - z0 with the same fraction for every ray
             const int p0z_i = (int)(c.fp0[2] >> 32);
@@ -564,16 +564,17 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
             const int ix_lo = max(0, (int)ceilf(fmaxf(ixc - ixr, -1.f)));
             const int ix_hi = min(g.ndx - 1, (int)floorf(fminf(ixc + ixr, (float)g.ndx)));
             if (ix_lo > ix_hi) continue;
-            const int n_rows_w = (ix_hi - ix_lo - wv) >= 0 ? (ix_hi - ix_lo - wv) / ADJ_WAVES + 1 : 0;
+            const int n_rows_w = ix_hi - ix_lo + 1;
             const float fp0x = (float)c.p0[0] - (float)x0, fp0y = (float)c.p0[1] - (float)y0;
             const float fux = (float)c.u[0], fuy = (float)c.u[1], fdx = (float)c.d[0], fdy = (float)c.d[1];
             const int iz = izoff + lane;
             const bool ray_ok = lane < ATZ && iz >= 0 && iz < g.ndz;   // the ray this lane owns (plane ATZ is halo only)
+            const int64_t ldx = (int64_t)lane * c.fd[0], ldy = (int64_t)lane * c.fd[1];   // sample `lane` of a chunk, relative to its first
 
             for (int r0 = 0; r0 < n_rows_w; r0 += 64) {
                 int v_jlo = 0, v_jhi = 0;
                 {
-                    const int rix = ix_lo + wv + ADJ_WAVES * (r0 + lane);
+                    const int rix = ix_lo + r0 + lane;
                     const float frix = (float)rix;
                     float t0 = 0.f, t1 = (float)(c.n - 1);
                     {
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
                 for (int r = 0; r < r_end; ++r) {
                     const int jlo = __builtin_amdgcn_readlane(v_jlo, r), jhi = __builtin_amdgcn_readlane(v_jhi, r);
                     if (jhi <= jlo) continue;
-                    const int ix = ix_lo + wv + ADJ_WAVES * (r0 + r);
+                    const int ix = ix_lo + r0 + r;
                     float *pr = proj + (size_t)c.slot * n_det + (size_t)ix * g.ndz + iz;
                     const int64_t rbx = c.fp0[0] + (int64_t)ix * c.fu[0] - orgx, rby = c.fp0[1] + (int64_t)ix * c.fu[1] - orgy;
                     float S = 0.f;            // forward: sum over samples of the x,y-interpolated plane `lane`
@@ -611,13 +612,17 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
                     }
                     for (int jc = jlo; jc < jhi; jc += 64) {
                         // one lane per SAMPLE: cell, ownership in x,y and the four x,y weights of sample jc + lane
-                        const int64_t px = rbx + (int64_t)(jc + lane) * c.fd[0], py = rby + (int64_t)(jc + lane) * c.fd[1];
+                        const int64_t px = rbx + (int64_t)jc * c.fd[0] + ldx, py = rby + (int64_t)jc * c.fd[1] + ldy;
                         const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32);
                         const bool own = (lx | ly) < (unsigned)ATX && jc + lane < jhi;
                         const unsigned t_e = own ? (__umul24(lx, ALY * ALZ) + __umul24(ly, ALZ)) * 4u : 0xffffffffu;
                         const float wx = (float)(unsigned)px * two_m32, wy = (float)(unsigned)py * two_m32;
                         const float t_w11 = wx * wy, t_w10 = wx - t_w11, t_w01 = wy - t_w11, t_w00 = 1.f - wx - t_w01;
+#ifdef TOMO_ABLATE_FLAT_SAMPLES          // development build only: skip the sample loop at run time (keeps all set-up alive)
+                        const int cnt = g.step < 0.0 ? min(64, jhi - jc) : 0;
+#else
                         const int cnt = min(64, jhi - jc);
+#endif
                         for (int jj = 0; jj < cnt; ++jj) {
                             const unsigned e4 = (unsigned)__builtin_amdgcn_readlane((int)t_e, jj);
                             if (e4 == 0xffffffffu) continue;                       // sample not in this tile's x,y cells (scalar branch)
