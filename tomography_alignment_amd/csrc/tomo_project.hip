@@ -510,21 +510,24 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
 // row (forward: to the accumulated plane sums S_l, S_{l+1}; adjoint: to the sinogram row before the loop).
 // Same sums as k_tile, regrouped: ~11 VALU per sample instead of ~32.
 // ------------------------------------------------------------------------------------------------
+#define FTZ 63              // flat kernels: 63 owned planes + halo = all 64 lanes busy
+#define FLZ (FTZ + 1)
+
 template <bool FWD>
 __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
                                                               float *__restrict__ vol, TomoGeomC g, const unsigned *__restrict__ absmax_bits,
                                                               float weight_bound, int tile_x0)
 {
-    __shared__ int acc[ALX * ALY * ALZ];
+    __shared__ int acc[ALX * ALY * FLZ];
     const float *img = (const float *)acc;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int z0 = -1 + (int)blockIdx.x * ATZ, y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + ((int)blockIdx.z + tile_x0) * ATX;
+    const int z0 = -1 + (int)blockIdx.x * FTZ, y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + ((int)blockIdx.z + tile_x0) * ATX;
     float scale = 1.f, inv_scale = 1.f;
     if (FWD) {
         bool any_nz = false;
-        for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) {
-            const int lz = e % ALZ, t2 = e / ALZ, ly = t2 % ALY, lx = t2 / ALY;
+        for (int e = threadIdx.x; e < ALX * ALY * FLZ; e += ADJ_WAVES * 64) {
+            const int lz = e % FLZ, t2 = e / FLZ, ly = t2 % ALY, lx = t2 / ALY;
             const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
             float v = 0.f;
             if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz) v = vol[((size_t)gx * g.ny + gy) * g.nz + gz];
@@ -537,14 +540,14 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
         if (!(ymax > 0.f)) return;
         scale = 1073741824.f / ((float)min(n_proj, ADJ_BATCH) * ymax * weight_bound);
         inv_scale = 1.f / scale;
-        for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) acc[e] = 0;
+        for (int e = threadIdx.x; e < ALX * ALY * FLZ; e += ADJ_WAVES * 64) acc[e] = 0;
         __syncthreads();
     }
     const float bcx = (float)x0 + 0.5f * ATX, bcy = (float)y0 + 0.5f * ATY;
     const int64_t orgx = (int64_t)x0 << 32, orgy = (int64_t)y0 << 32;
     const size_t n_det = (size_t)g.ndx * g.ndz;
     const float two_m32 = 2.3283064365386963e-10f;
-    const unsigned lane4 = (unsigned)min(lane, ALZ - 1) * 4u;      // lanes 61..63 alias the halo plane with zero weight
+    const unsigned lane4 = (unsigned)min(lane, FLZ - 1) * 4u;      // lanes 61..63 alias the halo plane with zero weight
 
     const int batch = FWD ? n_proj : ADJ_BATCH;
     for (int ip0 = 0; ip0 < n_proj; ip0 += batch) {
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
             const int p0z_i = (int)(c.fp0[2] >> 32);
             const float wcz = (float)(unsigned)c.fp0[2] * two_m32, wfz = 1.f - wcz;
             const int izoff = z0 - p0z_i;                              // iz = lane + izoff
-            if (izoff + ATZ <= 0 || izoff >= g.ndz) continue;          // no ray of this projection floors into the tile's z range
+            if (izoff + FTZ <= 0 || izoff >= g.ndz) continue;          // no ray of this projection floors into the tile's z range
             // detector rows crossing the tile's x,y footprint (2-D: a linear functional over a rectangle)
             const float qx = bcx - (float)c.p0[0], qy = bcy - (float)c.p0[1];
             const float m00 = (float)c.minv[0][0], m01 = (float)c.minv[0][1];
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
             const float fp0x = (float)c.p0[0] - (float)x0, fp0y = (float)c.p0[1] - (float)y0;
             const float fux = (float)c.u[0], fuy = (float)c.u[1], fdx = (float)c.d[0], fdy = (float)c.d[1];
             const int iz = izoff + lane;
-            const bool ray_ok = lane < ATZ && iz >= 0 && iz < g.ndz;   // the ray this lane owns (plane ATZ is halo only)
+            const bool ray_ok = lane < FTZ && iz >= 0 && iz < g.ndz;   // the ray this lane owns (the last plane is halo only)
             const int64_t ldx = (int64_t)lane * c.fd[0], ldy = (int64_t)lane * c.fd[1];   // sample `lane` of a chunk, relative to its first
 
             for (int r0 = 0; r0 < n_rows_w; r0 += 64) {
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
                         const int64_t px = rbx + (int64_t)jc * c.fd[0] + ldx, py = rby + (int64_t)jc * c.fd[1] + ldy;
                         const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32);
                         const bool own = (lx | ly) < (unsigned)ATX && jc + lane < jhi;
-                        const unsigned t_e = own ? (__umul24(lx, ALY * ALZ) + __umul24(ly, ALZ)) * 4u : 0xffffffffu;
+                        const unsigned t_e = own ? (__umul24(lx, ALY * FLZ) + __umul24(ly, FLZ)) * 4u : 0xffffffffu;
                         const float wx = (float)(unsigned)px * two_m32, wy = (float)(unsigned)py * two_m32;
                         const float t_w11 = wx * wy, t_w10 = wx - t_w11, t_w01 = wy - t_w11, t_w00 = 1.f - wx - t_w01;
 #ifdef TOMO_ABLATE_FLAT_SAMPLES          // development build only: skip the sample loop at run time (keeps all set-up alive)
@@ -633,15 +636,15 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
                             if (FWD) {
                                 const float *q = (const float *)((const char *)img + (e4 + lane4));
                                 S = fmaf(w00, q[0], S);
-                                S = fmaf(w01, q[ALZ], S);
-                                S = fmaf(w10, q[ALY * ALZ], S);
-                                S = fmaf(w11, q[ALY * ALZ + ALZ], S);
+                                S = fmaf(w01, q[FLZ], S);
+                                S = fmaf(w10, q[ALY * FLZ], S);
+                                S = fmaf(w11, q[ALY * FLZ + FLZ], S);
                             } else {
                                 int *q = (int *)((char *)acc + (e4 + lane4));
                                 atomicAdd(q, cvt_round_i32(yt * w00));
-                                atomicAdd(q + ALZ, cvt_round_i32(yt * w01));
-                                atomicAdd(q + ALY * ALZ, cvt_round_i32(yt * w10));
-                                atomicAdd(q + ALY * ALZ + ALZ, cvt_round_i32(yt * w11));
+                                atomicAdd(q + FLZ, cvt_round_i32(yt * w01));
+                                atomicAdd(q + ALY * FLZ, cvt_round_i32(yt * w10));
+                                atomicAdd(q + ALY * FLZ + FLZ, cvt_round_i32(yt * w11));
                             }
                         }
                     }
@@ -654,11 +657,11 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
         }
         if (FWD) break;
         __syncthreads();
-        for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) {
+        for (int e = threadIdx.x; e < ALX * ALY * FLZ; e += ADJ_WAVES * 64) {
             const int v = acc[e];
             if (v != 0) {
                 acc[e] = 0;
-                const int lz = e % ALZ, t2 = e / ALZ, ly = t2 % ALY, lx = t2 / ALY;
+                const int lz = e % FLZ, t2 = e / FLZ, ly = t2 % ALY, lx = t2 / ALY;
                 const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
                 if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz)
                     atomicAdd(&vol[((size_t)gx * g.ny + gy) * g.nz + gz], (float)v * inv_scale);
@@ -909,7 +912,7 @@ static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, b
     return TOMO_OK;
 }
 
-static inline dim3 tile_grid(const TomoGeomC &g) { return dim3((g.nz + 1 + ATZ - 1) / ATZ, (g.ny + 1 + ATY - 1) / ATY, (g.nx + 1 + ATX - 1) / ATX); }
+static inline dim3 tile_grid(const TomoGeomC &g, int tz = ATZ) { return dim3((g.nz + 1 + tz - 1) / tz, (g.ny + 1 + ATY - 1) / ATY, (g.nx + 1 + ATX - 1) / ATX); }
 
 extern "C" int tomo_forward(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_vol, float *d_proj)
 {
@@ -932,8 +935,8 @@ extern "C" int tomo_forward(tomo_ctx *ctx, const double *h_poses, int n_proj, co
             const AdjC *d_c = (const AdjC *)ctx->d_stage;
             TOMO_HIP(ctx, hipMemsetAsync(d_proj, 0, n_det * (size_t)n_proj * sizeof(float), ctx->stream));
             if (n_flat > 0)
-                TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_tile_flat<true>, grid, dim3(ADJ_WAVES * 64), 0, d_c, n_flat, d_proj, (float *)d_vol, g,
-                            (const unsigned *)nullptr, 1.f, 0);
+                TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_tile_flat<true>, tile_grid(g, FTZ), dim3(ADJ_WAVES * 64), 0, d_c, n_flat, d_proj,
+                            (float *)d_vol, g, (const unsigned *)nullptr, 1.f, 0);
             if (n_proj > n_flat)
                 TOMO_LAUNCH(ctx, "k_fwd_tile", k_tile<true>, grid, dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, d_proj, (float *)d_vol,
                             g, (const unsigned *)nullptr, 1.f, 0);
@@ -1000,9 +1003,12 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
     const int64_t n_y = (int64_t)n_det * n_proj;
     TOMO_LAUNCH(ctx, "k_absmax", k_absmax, dim3((unsigned)std::min<int64_t>((n_y + 255) / 256, 2048)), dim3(256), 0, d_proj, n_y, d_absmax);
     const AdjC *d_c = (const AdjC *)ctx->d_stage;
-    if (n_flat > 0)
-        TOMO_LAUNCH(ctx, "k_adj_tile_flat", k_tile_flat<false>, grid, dim3(ADJ_WAVES * 64), 0, d_c, n_flat, (float *)d_proj, d_vol, g,
+    if (n_flat > 0) {
+        dim3 fgrid = tile_grid(g, FTZ);
+        fgrid.z = grid.z;
+        TOMO_LAUNCH(ctx, "k_adj_tile_flat", k_tile_flat<false>, fgrid, dim3(ADJ_WAVES * 64), 0, d_c, n_flat, (float *)d_proj, d_vol, g,
                     (const unsigned *)d_absmax, (float)weight_bound, xt0);
+    }
     if (n_proj > n_flat)
         TOMO_LAUNCH(ctx, "k_adj_tile", k_tile<false>, grid, dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, (float *)d_proj, d_vol, g,
                     (const unsigned *)d_absmax, (float)weight_bound, xt0);
