@@ -34,6 +34,11 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-le
 
 
 def main():
+    # Libraries (RCCL prints a version banner at communicator init) must not pollute the ONE JSON line on stdout:
+    # send everything written to fd 1 during the run to stderr and keep the real stdout for the final line.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -161,12 +166,12 @@ def main():
     its = args.steps / elapsed
     out = {
         "metric": "sirt_iterations_per_sec",
-        "value": round(its, 5),
+        "value": round(its, 6),
         "unit": "it/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -186,11 +191,12 @@ def main():
 
     if not args.no_align:
         del solver
-        out["alignment_gradient"] = align_rate(comm, ctx, rank, world)
+        out["alignment_gradient"] = align_rate(comm, ctx, rank, world, N=min(512, max(32, N // 2)), n_proj=720 if N >= 1024 else max(8, n_proj // 2))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(be, d_true, N, n_proj, phi)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or args.force_sharded:
         comm.close()
 

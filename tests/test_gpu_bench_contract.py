@@ -1,0 +1,44 @@
+"""bench.py prints ONE JSON line with the driver's contract fields plus `roofline` and `cpu_baseline` (checked on a tiny
+workload so the test takes seconds)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "64", "--angles", "48", "--steps", "2", "--warmup", "1"] + extra,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_json_contract():
+    d = _run([])
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                     ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
+        assert isinstance(d[key], typ), key
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "it/s" and d["dtype"] == "f32" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-2
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["kernel"].startswith(("k_fwd", "k_adj")) and r["achieved"] > 0 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "it/s" and c["value"] > 0 and isinstance(c["sample"], str)
+    assert d["value"] > 100 * c["value"]
+    a = d["alignment_gradient"]
+    assert a["evals_per_sec"] > 0
+
+
+def test_bench_sharded_code_path_on_one_gpu():
+    d = _run(["--force-sharded", "--no-cpu-baseline", "--no-align", "--perturbed"])
+    assert d["value"] > 0 and d["kernels"]["k_adj_tile"]["launches_per_step"] >= 2      # x-slab pipelined back-projection
