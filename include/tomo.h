@@ -86,7 +86,10 @@ TOMO_API int tomo_sync(tomo_ctx *ctx);
 /* Integer knobs; unknown keys are TOMO_ERR_ARG.
  *   "fwd_variant" 1 ray-driven (plain), 2 ray-driven (SGPR block base), 3 LDS tile kernels (default)
  *   "adj_variant" 1 global float atomics, 2 LDS tile kernels with fixed-point accumulation (default)
- *   "tile_flat"   1 (default): untilted projections (alpha = beta = 0, detector-z pitch 1) take the flat tile kernels */
+ *   "tile_flat"   1 (default): untilted projections (alpha = beta = 0, detector-z pitch 1) take the flat tile kernels
+ *   "reuse_staged_volume" 1: the caller vouches that the volume passed to tomo_proj_grad / tomo_cost_grad / the ray-driven
+ *                 forward has not changed since the previous such call with the same pointer, so its zero-padded staging
+ *                 copy is reused (alignment loops evaluate hundreds of poses against one volume); default 0 */
 TOMO_API int tomo_set_option(tomo_ctx *ctx, const char *key, int value);
 
 /* Geometry: replaces passing a `Geometry` object to utilities/ray_voxel_utilities.py:53,113. */

@@ -200,3 +200,26 @@ def test_pipelined_allreduce_path_matches_plain(shepp32):
     be = HipBackend(geo, ctx=ctx)
     assert be.xslab_info() == (3, 16)
     comm.close()
+
+
+def test_staged_volume_reuse_is_safe(shepp32):
+    """Alignment loops evaluate many poses against one pinned volume: the zero-padded staging copy is reused, and a changed
+    volume (new host contents, or a device buffer after invalidate_volume()) is picked up."""
+    from tomography_alignment_amd.utilities import projection_operators
+    geo = geom(1, 32)
+    P = projection_operators.ProjectionMatrix(geo)
+    pose = dict(alpha=0.01, beta=-0.02, phi=0.8, xyz_shift=np.array([0.5, 0., -0.7]), cor_shift=np.zeros(3))
+    x = shepp32.copy()
+    p1, g1 = P.projection_gradient(x, **pose)
+    p2, _ = P.projection_gradient(x, **pose)            # staged copy reused
+    assert np.array_equal(p1, p2) and P._vol_staged
+    x2 = 2.0 * x
+    p3, g3 = P.projection_gradient(x2, **pose)          # new host contents: re-uploaded and re-staged
+    assert rel_max(p3, 2.0 * p1) < 1e-6 and rel_max(g3, 2.0 * g1) < 1e-6
+    d = P.backend.upload(x)
+    p4, _ = P.projection_gradient(d, **pose)
+    assert rel_max(p4, p1) < 1e-7
+    d.upload(3.0 * x)                                   # mutated in place behind the operator's back ...
+    P.invalidate_volume()                               # ... so the caller says so
+    p5, _ = P.projection_gradient(d, **pose)
+    assert rel_max(p5, 3.0 * p1) < 1e-6

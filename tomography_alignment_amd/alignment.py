@@ -39,6 +39,7 @@ class BatchEvaluator(object):
         self._b_all = backend.upload(self.b_host)
         self.cor = np.zeros(self.n) if cor_shift is None else np.asarray(cor_shift, np.float64).reshape(self.n, -1)[:, 0]
         self._gather = None
+        self._staged = False
         self.n_launch = 0
         self.n_eval = 0
 
@@ -59,7 +60,16 @@ class BatchEvaluator(object):
             b.upload(self.b_host[idx])            # host-side gather of the active rows (few MB per round)
         self.n_launch += 1
         self.n_eval += m
-        return self.be.cost_grad(np.ascontiguousarray(poses), self.vol, b)
+        ctx = getattr(self.be, "ctx", None)
+        if ctx is not None:                     # self.vol is pinned for the evaluator's lifetime: stage it once
+            ctx.set_option("reuse_staged_volume", 1 if self._staged else 0)
+        try:
+            out = self.be.cost_grad(np.ascontiguousarray(poses), self.vol, b)
+            self._staged = True
+        finally:
+            if ctx is not None:
+                ctx.set_option("reuse_staged_volume", 0)
+        return out
 
 
 class _Scheduler(object):

@@ -29,6 +29,8 @@ struct tomo_ctx {
     float *d_volpad = nullptr;
     size_t volpad_elems = 0;
     bool halo_dirty = true;
+    const void *staged_src = nullptr;   // device pointer whose contents the padded copy currently holds
+    int reuse_staged = 0;               // caller vouches: contents of staged_src unchanged since it was staged
     // per-projection constants (pinned host staging + device)
     void *h_stage = nullptr;
     void *d_stage = nullptr;

@@ -69,7 +69,7 @@ class AlignmentUtilities(object):
         if self._b_dev is None:
             self._b_dev = be.upload(np.asarray(self.proj, np.float32).ravel())
         pose = po.pose_row(alpha, beta, phi, t, self._cor())
-        cost, g6 = be.cost_grad(pose, vol, self._b_dev)
+        cost, g6 = po.pinned_call(be.cost_grad, pose, vol, self._b_dev)
         self._memo_key, self._memo_val = key, (float(cost[0]), g6[0].copy())
         return self._memo_val
 

@@ -184,6 +184,7 @@ class ProjectionMatrix(object):
         self._backend = backend
         self._vol_key = None
         self._vol_dev = None
+        self._vol_staged = False      # True once the library has staged the pinned volume and nothing has changed it since
         self._pg_bufs = None
 
     @property
@@ -227,6 +228,8 @@ class ProjectionMatrix(object):
         """Pin `rec` (host array or DeviceArray) in HBM for subsequent projection_gradient calls."""
         be = self.backend
         if be.is_buffer(rec):
+            if self._vol_key != ("dev", id(rec)):
+                self._vol_staged = False
             self._vol_dev, self._vol_key = rec, ("dev", id(rec))
             return rec
         a = np.asarray(rec)
@@ -239,7 +242,26 @@ class ProjectionMatrix(object):
                 self._vol_dev = be.empty(flat.size)
             self._vol_dev.upload(flat)
             self._vol_key = key
+            self._vol_staged = False
         return self._vol_dev
+
+    def pinned_call(self, fn, *args, **kw):
+        """Run a proj_grad / cost_grad backend call on the pinned volume, letting the library reuse its staged (zero-padded)
+        copy when the pinned contents have not changed since the last such call.  A DeviceArray passed by the caller is only
+        trusted between calls that pin the same object: whoever mutates it in place must call `invalidate_volume()`."""
+        ctx = getattr(self.backend, "ctx", None)
+        if ctx is None:
+            return fn(*args, **kw)
+        ctx.set_option("reuse_staged_volume", 1 if self._vol_staged else 0)
+        try:
+            out = fn(*args, **kw)
+            self._vol_staged = True
+        finally:
+            ctx.set_option("reuse_staged_volume", 0)
+        return out
+
+    def invalidate_volume(self):
+        self._vol_staged = False
 
     def pose_row(self, alpha, beta, phi, xyz_shift, cor_shift):
         return _lib.poses_array([phi], [alpha], [beta], np.asarray(xyz_shift, np.float64).reshape(1, 3),
@@ -251,7 +273,7 @@ class ProjectionMatrix(object):
         if self._pg_bufs is None:
             self._pg_bufs = (be.empty(be.n_det), be.empty(6 * be.n_det))
         p_dev, g_dev = self._pg_bufs
-        be.proj_grad(self.pose_row(alpha, beta, phi, xyz_shift, cor_shift), vol, p_dev, g_dev, 0)
+        self.pinned_call(be.proj_grad, self.pose_row(alpha, beta, phi, xyz_shift, cor_shift), vol, p_dev, g_dev, 0)
         proj_img = p_dev.download().astype(self.precision, copy=False)
         gradient = g_dev.download().astype(self.precision, copy=False)
         return proj_img.ravel(), gradient.reshape(6, -1)
