@@ -102,10 +102,12 @@ def test_voxel_mask_step_and_detector_shape(PM, orc):
     assert rel_max(A.T.dot(y), ref.T.dot(y)) < TOL
 
 
-def test_projection_gradient_vs_reference_golden(PM, shepp32):
+@pytest.mark.parametrize("grad_variant", [1, 2])
+def test_projection_gradient_vs_reference_golden(PM, shepp32, grad_variant):
     g = golden("g3_proj_grad")
     geo, _ = geo_pair(1, 32)
     P = PM(geo, precision=np.float64)
+    P.backend.ctx.set_option("grad_variant", grad_variant)
     for i in range(3):          # generic poses
         p, gr = P.projection_gradient(shepp32, g["alpha"][i], g["beta"][i], g["phi"][i], g["xyz"][i], g["cor"][i])
         assert gr.shape == (6, 1024)
@@ -373,3 +375,26 @@ def test_alignment_gradient_at_128_vs_oracle(PM, orc):
     assert rel_max(p, p0) < TOL
     for k in range(6):
         assert rel_max(g[k], g0[k]) < TOL, k
+
+
+@pytest.mark.parametrize("shape,ndet", [((24, 20, 70), (24, 70)), ((16, 16, 5), (20, 9)), ((48, 40, 130), (50, 140))])
+def test_gradient_kernel_variants_agree_on_odd_shapes(PM, orc, shape, ndet):
+    """grad_variant 2 (four gathers + neighbour-lane shift) vs 1 (eight gathers) vs the oracle, incl. large tilts where the
+    neighbour lane often does not line up, rays that leave the volume, and detector rows shorter than a wave."""
+    from tomography_alignment_amd import _lib
+    rng = np.random.default_rng(31)
+    geo, og = geo_pair(1, None, ndet=ndet, shape=shape)
+    x = rng.uniform(0.1, 1, shape).astype(np.float32)
+    for pose in ((0.4, 0.0, 0.0, (0.3, 0.2, -0.4)), (1.3, np.deg2rad(3.0), np.deg2rad(-4.0), (2.5, -1.0, 3.0)), (2.4, 0.6, -0.5, (-4., 2., 6.))):
+        phi, alpha, beta, t = pose
+        t = np.array(t)
+        want_p, want_g = orc.projection_gradient(og, x, alpha, beta, phi, t, np.array([0.7, 0., 0.]), precision=np.float64)
+        out = {}
+        for v in (1, 2):
+            P = PM(geo, precision=np.float64)
+            P.backend.ctx.set_option("grad_variant", v)
+            out[v] = P.projection_gradient(x, alpha, beta, phi, t, np.array([0.7, 0., 0.]))
+            assert rel_max(out[v][0], want_p) < TOL
+            for k in range(6):
+                assert rel_max(out[v][1][k], want_g[k]) < TOL, (v, k)
+        assert rel_max(out[2][0], out[1][0]) < 5e-6 and rel_max(out[2][1], out[1][1]) < 5e-6    # float32 lerps in another order

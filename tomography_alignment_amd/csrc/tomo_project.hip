@@ -820,6 +820,150 @@ __global__ __launch_bounds__(256) void k_proj_grad(const ProjC *__restrict__ pcs
 }
 
 // ------------------------------------------------------------------------------------------------
+// projection + gradient, variant 2: half the gather traffic.  Lanes run along detector-z, so lane l's upper-z corner
+// (cell z+1) is normally lane l+1's lower-z corner (cell z): every lane loads only its 4 lower-z corners (one dword each,
+// wave-uniform SGPR block base + 32-bit lane offset as in k_fwd_v2) and receives the 4 upper-z values from its neighbour by a
+// lane shift; where the neighbour does not line up (last lane, lane idle, or a tilt-induced cell step) the lane loads them
+// itself -- same values either way.  The block loop is wave-uniform so that the shift always reads live lanes.
+// ------------------------------------------------------------------------------------------------
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ pcs, const GradC *__restrict__ gcs,
+                                                      const float *__restrict__ vp, float *__restrict__ proj,
+                                                      float *__restrict__ grad, const float *__restrict__ bvec,
+                                                      float *__restrict__ resid, double *__restrict__ red, TomoGeomC g,
+                                                      int row_order)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ix = blockIdx.y * 4 + wv, ip = blockIdx.z;
+    int iz = blockIdx.x * 64 + lane;
+    const bool valid = (ix < g.ndx) && (iz < g.ndz);
+    const int ixc = min(ix, g.ndx - 1);
+    if (iz >= g.ndz) iz = g.ndz - 1;
+    const ProjC &c = pcs[ip];
+    const GradC &gc = gcs[ip];
+    RayCtx r;
+    ray_setup(c, g, ixc, iz, valid, r);
+    const bool nonempty = r.j1 > r.j0;
+    const int J0 = __builtin_amdgcn_readfirstlane(wave_min_i32(nonempty ? r.j0 : INT_MAX));
+    const int J1 = __builtin_amdgcn_readfirstlane(wave_max_i32(nonempty ? r.j1 : 0));
+    const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
+    const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;
+    const float sfs = (float)(g.step / c.rlen);
+    double val = 0.0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
+    for (int jb = J0; jb < J1; jb += TOMO_JB) {
+        int ia[3];
+        float f0[3];
+        tomo_block_anchor(r.b, r.d, jb, ia, f0);
+        const int64_t lin = ((int64_t)(ia[0] + TOMO_HALO) * g.nyp + (ia[1] + TOMO_HALO)) * g.nzp + (ia[2] + TOMO_HALO);
+        const int64_t lin0 = readfirstlane_i64(lin);
+        const int delta = (int)(lin - lin0);
+        const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(delta));
+        const char *sb00 = (const char *)(vp + (lin0 + m));
+        const char *sb01 = sb00 + sy4;
+        const char *sb10 = sb00 + sx4;
+        const char *sb11 = sb10 + sy4;
+        const uint32_t off0 = (uint32_t)(delta - m) * 4u;
+        const int lo = max(r.j0, jb) - jb, hi = min(r.j1, jb + TOMO_JB) - jb;      // this lane's samples of the block
+        const int LO = __builtin_amdgcn_readfirstlane(wave_min_i32(hi > lo ? lo : INT_MAX));
+        const int HI = __builtin_amdgcn_readfirstlane(wave_max_i32(hi > lo ? hi : 0));
+        float av = 0.f, a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
+        for (int jj = LO; jj < HI; ++jj) {                                         // wave-uniform: all lanes execute the loads
+            const bool act = jj >= lo && jj < hi;
+            const float t = (float)jj;
+            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
+            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+            const float wx = x - fx, wy = y - fy, wz = z - fz;
+            // idle lanes must still load (the shift reads every lane): they borrow the address of the first active lane --
+            // always inside the padded volume -- and advertise an offset nobody can match
+            const unsigned long long am = __ballot(act);
+            if (am == 0ull) continue;
+            const uint32_t vo_own = off0 + __umul24((uint32_t)(int)fx, sx4) + __umul24((uint32_t)(int)fy, sy4) + ((uint32_t)(int)fz << 2);
+            const uint32_t vo_safe = (uint32_t)__builtin_amdgcn_readlane((int)vo_own, __builtin_ctzll(am));
+            const uint32_t vo = act ? vo_own : vo_safe;
+            const float v000 = *(const float *)(sb00 + vo), v010 = *(const float *)(sb01 + vo);
+            const float v100 = *(const float *)(sb10 + vo), v110 = *(const float *)(sb11 + vo);
+            const uint32_t adv = act ? vo : 0xfffffff0u;
+            const uint32_t nb = (uint32_t)__shfl_down((int)adv, 1, 64);
+            float v001 = __shfl_down(v000, 1, 64), v011 = __shfl_down(v010, 1, 64);
+            float v101 = __shfl_down(v100, 1, 64), v111 = __shfl_down(v110, 1, 64);
+            if (act && (lane == 63 || nb != vo + 4u)) {                            // neighbour is not my upper-z cell: load it myself
+                v001 = *(const float *)(sb00 + vo + 4); v011 = *(const float *)(sb01 + vo + 4);
+                v101 = *(const float *)(sb10 + vo + 4); v111 = *(const float *)(sb11 + vo + 4);
+            }
+            const float d00 = v001 - v000, d01 = v011 - v010, d10 = v101 - v100, d11 = v111 - v110;
+            const float c00 = fmaf(wz, d00, v000), c01 = fmaf(wz, d01, v010), c10 = fmaf(wz, d10, v100), c11 = fmaf(wz, d11, v110);
+            const float dz0 = fmaf(wy, d01 - d00, d00), dz1 = fmaf(wy, d11 - d10, d10);
+            const float gz = fmaf(wx, dz1 - dz0, dz0);
+            const float dy0 = c01 - c00, dy1 = c11 - c10;
+            const float e0 = fmaf(wy, dy0, c00), e1 = fmaf(wy, dy1, c10);
+            const float gy = fmaf(wx, dy1 - dy0, dy0);
+            const float gx = e1 - e0;
+            const float keep = act ? 1.f : 0.f;
+            const float sf = (float)(jb + jj) * sfs;
+            av = fmaf(keep, fmaf(wx, gx, e0), av);
+            const float kx = keep * gx, ky = keep * gy, kz = keep * gz;
+            a0x += kx; a0y += ky; a0z += kz;
+            a1x = fmaf(sf, kx, a1x); a1y = fmaf(sf, ky, a1y); a1z = fmaf(sf, kz, a1z);
+        }
+        val += (double)av;
+        s0[0] += (double)a0x; s0[1] += (double)a0y; s0[2] += (double)a0z;
+        s1[0] += (double)a1x; s1[1] += (double)a1y; s1[2] += (double)a1z;
+    }
+    const double s[3] = {gc.s00[0] + ixc * gc.sdx, gc.s00[1], gc.s00[2] + iz * gc.sdz};
+    double qv[3], gk[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) qv[a] = gc.ry[a][0] * s[0] + gc.ry[a][1] * s[1] + gc.ry[a][2] * s[2] + gc.t[a];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gk[k] = gc.rzx[0][k] * s0[0] + gc.rzx[1][k] * s0[1] + gc.rzx[2][k] * s0[2];
+    gk[3] = gk[4] = gk[5] = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double d3 = gc.a3[a][0] * qv[0] + gc.a3[a][1] * qv[1] + gc.a3[a][2] * qv[2];
+        const double d4 = gc.a4[a][0] * qv[0] + gc.a4[a][1] * qv[1] + gc.a4[a][2] * qv[2];
+        const double d5 = gc.a5[a][0] * s[0] + gc.a5[a][1] * s[1] + gc.a5[a][2] * s[2];
+        gk[3] += d3 * s0[a] + gc.app[0][a] * s1[a];
+        gk[4] += d4 * s0[a] + gc.app[1][a] * s1[a];
+        gk[5] += d5 * s0[a] + gc.app[2][a] * s1[a];
+    }
+    const size_t n_det = (size_t)g.ndx * g.ndz;
+    const size_t ray = (size_t)ixc * g.ndz + iz;
+    if (!FUSED) {
+        if (valid) {
+            proj[ray] = (float)val;
+            if (row_order == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) grad[k * n_det + ray] = (float)gk[k];
+            } else {
+                grad[0 * n_det + ray] = (float)gk[0]; grad[1 * n_det + ray] = (float)gk[1]; grad[2 * n_det + ray] = (float)gk[2];
+                grad[3 * n_det + ray] = (float)gk[4]; grad[4 * n_det + ray] = (float)gk[5]; grad[5 * n_det + ray] = (float)gk[3];
+            }
+        }
+    } else {
+        double part[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (valid) {
+            const float pv = (float)val;
+            const double res = (double)(bvec[(size_t)ip * n_det + ray] - pv);
+            if (resid) resid[(size_t)ip * n_det + ray] = (float)res;
+            part[0] = 0.5 * res * res;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) part[1 + k] = -(double)(float)gk[k] * res;
+        }
+        __shared__ double sh[4][7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const double w = wave_sum_d(part[k]);
+            if (lane == 0) sh[wv][k] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x < 7) {
+            const int k = threadIdx.x;
+            atomicAdd(&red[(size_t)ip * 7 + k], sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static int upload_projc(tomo_ctx *ctx, const double *h_poses, int n, bool with_grad, ProjC **d_pc, GradC **d_gc)
@@ -1101,8 +1245,12 @@ extern "C" int tomo_proj_grad(tomo_ctx *ctx, const double *h_pose, const float *
     GradC *d_gc = nullptr;
     rc = upload_projc(ctx, h_pose, 1, true, &d_pc, &d_gc);
     if (rc) return rc;
-    TOMO_LAUNCH(ctx, "k_proj_grad", k_proj_grad<false>, ray_grid(g, 1), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, d_proj, d_grad,
-                (const float *)nullptr, (float *)nullptr, (double *)nullptr, g, row_order);
+    if (ctx->grad_variant == 1)
+        TOMO_LAUNCH(ctx, "k_proj_grad", k_proj_grad<false>, ray_grid(g, 1), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, d_proj, d_grad,
+                    (const float *)nullptr, (float *)nullptr, (double *)nullptr, g, row_order);
+    else
+        TOMO_LAUNCH(ctx, "k_proj_grad", k_proj_grad_v2<false>, ray_grid(g, 1), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, d_proj, d_grad,
+                    (const float *)nullptr, (float *)nullptr, (double *)nullptr, g, row_order);
     return TOMO_OK;
 }
 
@@ -1123,8 +1271,12 @@ extern "C" int tomo_cost_grad(tomo_ctx *ctx, const double *h_poses, int n, const
     rc = upload_projc(ctx, h_poses, n, true, &d_pc, &d_gc);
     if (rc) return rc;
     TOMO_HIP(ctx, hipMemsetAsync(ctx->d_red, 0, sizeof(double) * (size_t)n * 7, ctx->stream));
-    TOMO_LAUNCH(ctx, "k_cost_grad", k_proj_grad<true>, ray_grid(g, n), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, (float *)nullptr,
-                (float *)nullptr, d_b, d_resid, ctx->d_red, g, 0);
+    if (ctx->grad_variant == 1)
+        TOMO_LAUNCH(ctx, "k_cost_grad", k_proj_grad<true>, ray_grid(g, n), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, (float *)nullptr,
+                    (float *)nullptr, d_b, d_resid, ctx->d_red, g, 0);
+    else
+        TOMO_LAUNCH(ctx, "k_cost_grad", k_proj_grad_v2<true>, ray_grid(g, n), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, (float *)nullptr,
+                    (float *)nullptr, d_b, d_resid, ctx->d_red, g, 0);
     TOMO_HIP(ctx, hipMemcpyAsync(ctx->h_red, ctx->d_red, sizeof(double) * (size_t)n * 7, hipMemcpyDeviceToHost, ctx->stream));
     TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < n; ++i) {
