@@ -86,8 +86,9 @@ TOMO_API int tomo_sync(tomo_ctx *ctx);
 /* Integer knobs; unknown keys are TOMO_ERR_ARG.
  *   "fwd_variant" 1 ray-driven (plain), 2 ray-driven (SGPR block base), 3 LDS tile kernels (default)
  *   "adj_variant" 1 global float atomics, 2 LDS tile kernels with fixed-point accumulation (default)
- *   "grad_variant" 1 (default) eight corner gathers per sample, 2 four gathers + neighbour-lane shift -- same results, measured
- *                  slower on gfx950 (the kernel is VALU-bound, not gather-bound)   (tomo_proj_grad / tomo_cost_grad)
+ *   "grad_variant" 1 plain kernel (per-lane 64-bit addressing, corner pairs as dwordx2 gathers), 2 (default) wave-uniform block
+ *                  base + 32-bit lane offsets, eight dword gathers, two samples in flight, pair-packed lerps and a cache-aware
+ *                  block order -- same sums, 1.3x faster at 512^3 x 720                (tomo_proj_grad / tomo_cost_grad)
  *   "tile_flat"   1 (default): untilted projections (alpha = beta = 0, detector-z pitch 1) take the flat tile kernels
  *   "reuse_staged_volume" 1: the caller vouches that the volume passed to tomo_proj_grad / tomo_cost_grad / the ray-driven
  *                 forward has not changed since the previous such call with the same pointer, so its zero-padded staging

@@ -398,3 +398,52 @@ def test_gradient_kernel_variants_agree_on_odd_shapes(PM, orc, shape, ndet):
             for k in range(6):
                 assert rel_max(out[v][1][k], want_g[k]) < TOL, (v, k)
         assert rel_max(out[2][0], out[1][0]) < 5e-6 and rel_max(out[2][1], out[1][1]) < 5e-6    # float32 lerps in another order
+
+
+@pytest.mark.parametrize("ndet", [(384, 340), (402, 350)])      # 96 ix groups (XCD swizzle) / 101 (plain)
+def test_cost_grad_cache_ordered_grid_vs_oracle(PM, orc, ndet):
+    """Volumes whose padded copy exceeds the Infinity Cache make grad_variant 2 walk the grid detector-z-chunk slowest
+    (csrc/tomo_project.hip: grad_zslow): same numbers as the oracle and as variant 1, every ray exactly once."""
+    from tomography_alignment_amd import _lib
+    shape = (400, 380, 340)
+    assert (shape[0] + 4) * (shape[1] + 4) * (shape[2] + 4) * 4 > 192 << 20
+    rng = np.random.default_rng(17)
+    geo, og = geo_pair(1, None, ndet=ndet, shape=shape)
+    # a SMOOTH object: the gradient of the trilinear interpolant jumps across cell faces, so on an object with sharp edges a
+    # sample within float32 rounding of a face (a few of the 5e7 here) changes a ray's gradient by O(1) against the float64
+    # oracle while its value does not move -- that would test luck, not the kernel
+    ax = [np.linspace(-1, 1, m) for m in shape]
+    X, Y, Z = np.meshgrid(*ax, indexing="ij", sparse=True)
+    x = ((1.0 + 0.5 * np.sin(5 * X + 1) * np.cos(4 * Y) * np.sin(3 * Z + 2)) * np.exp(-3.0 * (X ** 2 + 1.3 * Y ** 2 + Z ** 2))).astype(np.float32)
+    n, n_det = 3, ndet[0] * ndet[1]
+    phi = np.array([0.3, 1.9, 2.8]); alpha = np.deg2rad([1.5, -2.0, 0.0]); beta = np.deg2rad([-1.0, 0.7, 0.0])
+    xyz = np.array([[2.0, 0.5, -3.0], [-1.5, 0.0, 2.5], [0.0, 0.0, 0.0]]); cor = np.array([[0.4, 0, 0]] * 3)
+    b = np.zeros((n, n_det), np.float32)
+    want_c, want_g, scale_g, want_p = [], [], [], []
+    for i in range(n):
+        p, gr = orc.projection_gradient(og, x, alpha[i], beta[i], phi[i], xyz[i], cor[i])
+        b[i] = p + 0.5 * rng.standard_normal(n_det).astype(np.float32)
+        res = b[i].astype(np.float64) - p
+        want_p.append(p)
+        want_c.append(0.5 * np.dot(res, res))
+        want_g.append(np.dot(-gr.astype(np.float64), res))
+        scale_g.append(np.dot(np.abs(gr.astype(np.float64)), np.abs(res)))
+    poses = _lib.poses_array(phi, alpha, beta, xyz, cor)
+    P = PM(geo)
+    be = P.backend
+    vol, bd, resid = be.upload(x), be.upload(b), be.empty(n * n_det)
+    out = {}
+    for v in (2, 1):
+        be.ctx.set_option("grad_variant", v)
+        cost, g6 = be.cost_grad(poses, vol, bd, resid)
+        out[v] = (cost.copy(), g6.copy())
+        assert np.allclose(cost, want_c, rtol=1e-5), v
+        # the ray-direction translation telescopes to ~0 on an object that vanishes at the boundary, so errors are measured
+        # against the largest component of the same unit (translations / angles), the rel_max convention of this file
+        sc = np.array(scale_g)
+        sc = np.concatenate([np.repeat(sc[:, 0:3].max(axis=1, keepdims=True), 3, 1), np.repeat(sc[:, 3:6].max(axis=1, keepdims=True), 3, 1)], 1)
+        assert np.max(np.abs(g6 - np.array(want_g)) / sc) < TOL, v
+        r = resid.download().reshape(n, -1)
+        for i in range(n):
+            assert np.max(np.abs((b[i] - r[i]) - want_p[i])) / np.max(np.abs(want_p[i])) < TOL, (v, i)
+    assert np.allclose(out[1][0], out[2][0], rtol=1e-6)

@@ -820,11 +820,15 @@ __global__ __launch_bounds__(256) void k_proj_grad(const ProjC *__restrict__ pcs
 }
 
 // ------------------------------------------------------------------------------------------------
-// projection + gradient, variant 2: half the gather traffic.  Lanes run along detector-z, so lane l's upper-z corner
-// (cell z+1) is normally lane l+1's lower-z corner (cell z): every lane loads only its 4 lower-z corners (one dword each,
-// wave-uniform SGPR block base + 32-bit lane offset as in k_fwd_v2) and receives the 4 upper-z values from its neighbour by a
-// lane shift; where the neighbour does not line up (last lane, lane idle, or a tilt-induced cell step) the lane loads them
-// itself -- same values either way.  The block loop is wave-uniform so that the shift always reads live lanes.
+// projection + gradient, variant 2: the same sums as k_proj_grad with a cheaper sample (about 40 VALU instead of 59).
+//   * addressing as in k_fwd_v2: the sample blocks are walked in wave-uniform steps, the block bases are SGPR pairs and each
+//     lane carries ONE 32-bit byte offset for all eight corners (saddr + voffset loads): 3 integer ops instead of 14 64-bit ones;
+//   * eight dword gathers instead of four dwordx2 (see the note in the kernel: 3.5x cheaper in the L1 pipeline);
+//   * the lerps are written on (z, z+1) register pairs -- y first, then x, then z -- so that they map 1:1 onto
+//     v_pk_add_f32 / v_pk_fma_f32 without register shuffles.
+// (A version that loaded only the four lower-z corners and took the upper ones from the neighbouring lane by a lane shift was
+// measured 30 % SLOWER than variant 1: the kernel is VALU-bound, not gather-bound, and the shifts cost more than the loads.)
+// Only lanes inside their own [lo, hi) execute loads, all at addresses of samples inside the padded volume.
 // ------------------------------------------------------------------------------------------------
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ pcs, const GradC *__restrict__ gcs,
@@ -835,8 +839,20 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
 {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ix = blockIdx.y * 4 + wv, ip = blockIdx.z;
-    int iz = blockIdx.x * 64 + lane;
+    // Grid = (ix groups, projections, detector-z chunks), z chunk SLOWEST: all projections of one 64-row detector slab run
+    // back to back, so the volume slab they read (n^2 * 64 cells, 64 MB at 512^3) stays in the 256 MB Infinity Cache
+    // instead of the whole volume streaming from HBM once per projection.  Workgroups are dealt to the 8 XCDs round-robin
+    // in dispatch order, so the swizzle gives each XCD a contiguous range of ix groups (neighbouring rays share L2 lines).
+    // (Volumes that fit the cache anyway keep the plain order row_order < 16: z chunk fastest, projection slowest.)
+    int ix, ip, iz;
+    if (row_order & 16) {
+        const int nxg = gridDim.x;
+        const int xg = ((nxg & 7) == 0) ? ((int)(blockIdx.x & 7) * (nxg >> 3) + (int)(blockIdx.x >> 3)) : (int)blockIdx.x;
+        ix = xg * 4 + wv, ip = blockIdx.y, iz = blockIdx.z * 64 + lane;
+    } else {
+        ix = blockIdx.y * 4 + wv, ip = blockIdx.z, iz = blockIdx.x * 64 + lane;
+    }
+    row_order &= 15;
     const bool valid = (ix < g.ndx) && (iz < g.ndz);
     const int ixc = min(ix, g.ndx - 1);
     if (iz >= g.ndz) iz = g.ndz - 1;
@@ -850,6 +866,12 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
     const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
     const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;
     const float sfs = (float)(g.step / c.rlen);
+    // Eight DWORD gathers per sample, on purpose: with lanes on consecutive z cells a wave-wide global_load_dword costs
+    // 4.8 cycles of the CU's texture-address/L1 pipeline, a dwordx2 (or x4) 17 (tools/gather_bench.hip), and that pipeline
+    // is what bounds this kernel (TA_BUSY = 100 %, profiles/).  The z + 1 bases are offset by an SGPR the compiler cannot
+    // see through, or it would fuse each (z, z + 1) pair back into one dwordx2.
+    int four;
+    asm volatile("s_mov_b32 %0, 4" : "=s"(four));
     double val = 0.0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
     for (int jb = J0; jb < J1; jb += TOMO_JB) {
         int ia[3];
@@ -863,52 +885,69 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
         const char *sb01 = sb00 + sy4;
         const char *sb10 = sb00 + sx4;
         const char *sb11 = sb10 + sy4;
+        const char *sc00 = sb00 + four, *sc01 = sb01 + four, *sc10 = sb10 + four, *sc11 = sb11 + four;   // the z + 1 corners
         const uint32_t off0 = (uint32_t)(delta - m) * 4u;
         const int lo = max(r.j0, jb) - jb, hi = min(r.j1, jb + TOMO_JB) - jb;      // this lane's samples of the block
-        const int LO = __builtin_amdgcn_readfirstlane(wave_min_i32(hi > lo ? lo : INT_MAX));
-        const int HI = __builtin_amdgcn_readfirstlane(wave_max_i32(hi > lo ? hi : 0));
-        float av = 0.f, a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
-        for (int jj = LO; jj < HI; ++jj) {                                         // wave-uniform: all lanes execute the loads
-            const bool act = jj >= lo && jj < hi;
-            const float t = (float)jj;
-            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
-            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-            const float wx = x - fx, wy = y - fy, wz = z - fz;
-            // idle lanes must still load (the shift reads every lane): they borrow the address of the first active lane --
-            // always inside the padded volume -- and advertise an offset nobody can match
-            const unsigned long long am = __ballot(act);
-            if (am == 0ull) continue;
-            const uint32_t vo_own = off0 + __umul24((uint32_t)(int)fx, sx4) + __umul24((uint32_t)(int)fy, sy4) + ((uint32_t)(int)fz << 2);
-            const uint32_t vo_safe = (uint32_t)__builtin_amdgcn_readlane((int)vo_own, __builtin_ctzll(am));
-            const uint32_t vo = act ? vo_own : vo_safe;
-            const float v000 = *(const float *)(sb00 + vo), v010 = *(const float *)(sb01 + vo);
-            const float v100 = *(const float *)(sb10 + vo), v110 = *(const float *)(sb11 + vo);
-            const uint32_t adv = act ? vo : 0xfffffff0u;
-            const uint32_t nb = (uint32_t)__shfl_down((int)adv, 1, 64);
-            float v001 = __shfl_down(v000, 1, 64), v011 = __shfl_down(v010, 1, 64);
-            float v101 = __shfl_down(v100, 1, 64), v111 = __shfl_down(v110, 1, 64);
-            if (act && (lane == 63 || nb != vo + 4u)) {                            // neighbour is not my upper-z cell: load it myself
-                v001 = *(const float *)(sb00 + vo + 4); v011 = *(const float *)(sb01 + vo + 4);
-                v101 = *(const float *)(sb10 + vo + 4); v111 = *(const float *)(sb11 + vo + 4);
+        float av = 0.f;
+        f32x2 a0xy = {0.f, 0.f}, a1xy = {0.f, 0.f}, az = {0.f, 0.f};              // (S0x, S0y), (S1x, S1y), (S0z, S1z)
+        const float sfb = (float)jb * sfs;
+        // two samples per trip: all 16 gathers are issued before the first value is used (the kernel waits on memory 3/4 of
+        // the time; this doubles the loads in flight per wave).  An odd tail re-reads sample A's address and is masked out.
+        for (int jj = lo; jj < hi; jj += 2) {
+            const float ta = (float)jj, tb = ta + 1.f;
+            const bool two = jj + 1 < hi;
+            const float xa = fmaf(ta, dxf, f0[0]), ya = fmaf(ta, dyf, f0[1]), za = fmaf(ta, dzf, f0[2]);
+            const float xb = fmaf(tb, dxf, f0[0]), yb = fmaf(tb, dyf, f0[1]), zb = fmaf(tb, dzf, f0[2]);
+            const float fxa = floorf(xa), fya = floorf(ya), fza = floorf(za);
+            const float fxb = floorf(xb), fyb = floorf(yb), fzb = floorf(zb);
+            const uint32_t voa = off0 + __umul24((uint32_t)(int)fxa, sx4) + __umul24((uint32_t)(int)fya, sy4) + ((uint32_t)(int)fza << 2);
+            const uint32_t vob_ = off0 + __umul24((uint32_t)(int)fxb, sx4) + __umul24((uint32_t)(int)fyb, sy4) + ((uint32_t)(int)fzb << 2);
+            const uint32_t vob = two ? vob_ : voa;
+            const f32x2 a00 = {*(const float *)(sb00 + voa), *(const float *)(sc00 + voa)};
+            const f32x2 a01 = {*(const float *)(sb01 + voa), *(const float *)(sc01 + voa)};
+            const f32x2 a10 = {*(const float *)(sb10 + voa), *(const float *)(sc10 + voa)};
+            const f32x2 a11 = {*(const float *)(sb11 + voa), *(const float *)(sc11 + voa)};
+            const f32x2 b00 = {*(const float *)(sb00 + vob), *(const float *)(sc00 + vob)};
+            const f32x2 b01 = {*(const float *)(sb01 + vob), *(const float *)(sc01 + vob)};
+            const f32x2 b10 = {*(const float *)(sb10 + vob), *(const float *)(sc10 + vob)};
+            const f32x2 b11 = {*(const float *)(sb11 + vob), *(const float *)(sc11 + vob)};
+            {
+                const float wx = xa - fxa, wy = ya - fya, wz = za - fza;
+                const f32x2 dy0 = a01 - a00, dy1 = a11 - a10;          // d/dy on the x = 0 / x = 1 faces, at z and z + 1
+                const f32x2 c0 = a00 + wy * dy0, c1 = a10 + wy * dy1;  // y-lerped
+                const f32x2 dx = c1 - c0;                              // d/dx at z, z + 1
+                const f32x2 e = c0 + wx * dx;                          // x,y-lerped value at z, z + 1
+                const f32x2 dyx = dy0 + wx * (dy1 - dy0);              // d/dy at z, z + 1
+                const float gz = e.y - e.x;
+                const float gx = fmaf(wz, dx.y - dx.x, dx.x), gy = fmaf(wz, dyx.y - dyx.x, dyx.x);
+                av += fmaf(wz, gz, e.x);
+                const float sf = fmaf(ta, sfs, sfb);                   // (jb + jj) * step / |r0|, one rounding
+                const f32x2 gxy = {gx, gy}, one_sf = {1.f, sf};
+                a0xy += gxy;
+                a1xy += sf * gxy;
+                az += one_sf * gz;
             }
-            const float d00 = v001 - v000, d01 = v011 - v010, d10 = v101 - v100, d11 = v111 - v110;
-            const float c00 = fmaf(wz, d00, v000), c01 = fmaf(wz, d01, v010), c10 = fmaf(wz, d10, v100), c11 = fmaf(wz, d11, v110);
-            const float dz0 = fmaf(wy, d01 - d00, d00), dz1 = fmaf(wy, d11 - d10, d10);
-            const float gz = fmaf(wx, dz1 - dz0, dz0);
-            const float dy0 = c01 - c00, dy1 = c11 - c10;
-            const float e0 = fmaf(wy, dy0, c00), e1 = fmaf(wy, dy1, c10);
-            const float gy = fmaf(wx, dy1 - dy0, dy0);
-            const float gx = e1 - e0;
-            const float keep = act ? 1.f : 0.f;
-            const float sf = (float)(jb + jj) * sfs;
-            av = fmaf(keep, fmaf(wx, gx, e0), av);
-            const float kx = keep * gx, ky = keep * gy, kz = keep * gz;
-            a0x += kx; a0y += ky; a0z += kz;
-            a1x = fmaf(sf, kx, a1x); a1y = fmaf(sf, ky, a1y); a1z = fmaf(sf, kz, a1z);
+            {
+                const float keep = two ? 1.f : 0.f;
+                const float wx = xb - fxb, wy = yb - fyb, wz = zb - fzb;
+                const f32x2 dy0 = b01 - b00, dy1 = b11 - b10;
+                const f32x2 c0 = b00 + wy * dy0, c1 = b10 + wy * dy1;
+                const f32x2 dx = c1 - c0;
+                const f32x2 e = c0 + wx * dx;
+                const f32x2 dyx = dy0 + wx * (dy1 - dy0);
+                const float gz = keep * (e.y - e.x);
+                const float gx = keep * fmaf(wz, dx.y - dx.x, dx.x), gy = keep * fmaf(wz, dyx.y - dyx.x, dyx.x);
+                av = fmaf(keep, fmaf(wz, e.y - e.x, e.x), av);
+                const float sf = fmaf(tb, sfs, sfb);
+                const f32x2 gxy = {gx, gy}, one_sf = {1.f, sf};
+                a0xy += gxy;
+                a1xy += sf * gxy;
+                az += one_sf * gz;
+            }
         }
         val += (double)av;
-        s0[0] += (double)a0x; s0[1] += (double)a0y; s0[2] += (double)a0z;
-        s1[0] += (double)a1x; s1[1] += (double)a1y; s1[2] += (double)a1z;
+        s0[0] += (double)a0xy.x; s0[1] += (double)a0xy.y; s0[2] += (double)az.x;
+        s1[0] += (double)a1xy.x; s1[1] += (double)a1xy.y; s1[2] += (double)az.y;
     }
     const double s[3] = {gc.s00[0] + ixc * gc.sdx, gc.s00[1], gc.s00[2] + iz * gc.sdz};
     double qv[3], gk[6];
@@ -985,6 +1024,13 @@ static int upload_projc(tomo_ctx *ctx, const double *h_poses, int n, bool with_g
 }
 
 static inline dim3 ray_grid(const TomoGeomC &g, int n_proj) { return dim3((g.ndz + 63) / 64, (g.ndx + 3) / 4, n_proj); }
+// k_proj_grad_v2 picks its block order from bit 4 of row_order: detector-z chunk slowest when the padded volume is larger than
+// the Infinity Cache can keep (about 192 MB to leave room for the rest) and several projections share it
+static inline bool grad_zslow(const TomoGeomC &g, int n_proj) { return n_proj > 1 && (size_t)g.nxp * g.nyp * g.nzp * 4 > ((size_t)192 << 20); }
+static inline dim3 grad_grid(const TomoGeomC &g, int n_proj)
+{
+    return grad_zslow(g, n_proj) ? dim3((g.ndx + 3) / 4, n_proj, (g.ndz + 63) / 64) : ray_grid(g, n_proj);
+}
 
 #define TOMO_MAX_GRID_Z 65535
 
@@ -1275,8 +1321,8 @@ extern "C" int tomo_cost_grad(tomo_ctx *ctx, const double *h_poses, int n, const
         TOMO_LAUNCH(ctx, "k_cost_grad", k_proj_grad<true>, ray_grid(g, n), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, (float *)nullptr,
                     (float *)nullptr, d_b, d_resid, ctx->d_red, g, 0);
     else
-        TOMO_LAUNCH(ctx, "k_cost_grad", k_proj_grad_v2<true>, ray_grid(g, n), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, (float *)nullptr,
-                    (float *)nullptr, d_b, d_resid, ctx->d_red, g, 0);
+        TOMO_LAUNCH(ctx, "k_cost_grad", k_proj_grad_v2<true>, grad_grid(g, n), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, (float *)nullptr,
+                    (float *)nullptr, d_b, d_resid, ctx->d_red, g, grad_zslow(g, n) ? 16 : 0);
     TOMO_HIP(ctx, hipMemcpyAsync(ctx->h_red, ctx->d_red, sizeof(double) * (size_t)n * 7, hipMemcpyDeviceToHost, ctx->stream));
     TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < n; ++i) {
