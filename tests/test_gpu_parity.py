@@ -447,3 +447,55 @@ def test_cost_grad_cache_ordered_grid_vs_oracle(PM, orc, ndet):
         for i in range(n):
             assert np.max(np.abs((b[i] - r[i]) - want_p[i])) / np.max(np.abs(want_p[i])) < TOL, (v, i)
     assert np.allclose(out[1][0], out[2][0], rtol=1e-6)
+
+
+def test_properties_at_full_size_1024():
+    """BASELINE.json configs[2] size (1024^3 volume, 1024^2 detector), a few angles, everything resident on the device:
+    adjointness, linearity, the tile kernels against the ray-driven ones, flat against general tile kernels, and the
+    x-slab adjoint (the multi-GPU pipeline's unit) against the whole adjoint."""
+    from tomography_alignment_amd import _lib
+    from tomography_alignment_amd.backend import HipBackend
+    from tomography_alignment_amd.utilities.generate_phantom import SHEPP_LOGAN
+    N, n = 1024, 6
+    geo, _ = geo_pair(n, N)
+    be = HipBackend(geo)
+    rng = np.random.default_rng(5)
+    phi = np.linspace(0.1, 3.0, n)
+    tilt = _lib.poses_array(phi, np.deg2rad(rng.uniform(-1, 1, n)), np.deg2rad(rng.uniform(-1, 1, n)),
+                            np.column_stack([rng.uniform(-2, 2, n), np.zeros(n), rng.uniform(-2, 2, n)]), np.zeros((n, 3)))
+    flat = _lib.poses_array(phi, np.zeros(n), np.zeros(n), np.column_stack([rng.uniform(-2, 2, n), np.zeros(n), rng.uniform(-2, 2, n)]),
+                            np.zeros((n, 3)))
+    n_vox, n_sino = N ** 3, n * N * N
+    x = be.phantom(be.empty(n_vox), (N, N, N), SHEPP_LOGAN)
+    y = be.upload(rng.uniform(0, 1, n_sino).astype(np.float32))
+    ax, aty, tmp, tmp2 = be.empty(n_sino), be.empty(n_vox), be.empty(n_sino), be.empty(n_vox)
+    for poses in (tilt, flat):
+        be.forward(poses, x, ax)
+        be.adjoint(poses, y, aty)
+        lhs, rhs = be.dot(ax, y), be.dot(x, aty)
+        assert abs(lhs - rhs) / abs(lhs) < 1e-5                         # <Ax, y> = <x, A^T y>
+        # linearity: A(x + 2 A^T y) = Ax + 2 A(A^T y)
+        be.copy(tmp2, x); be.axpy(tmp2, aty, 2.0)
+        lin = be.forward(poses, tmp2, be.empty(n_sino)).download()
+        want = ax.download() + 2.0 * be.forward(poses, aty, tmp).download()
+        assert rel_max(lin, want) < TOL
+        del lin, want
+        # tile kernels vs the ray-driven kernels (independent code paths, same sums)
+        be.ctx.set_option("fwd_variant", 2)
+        assert np.sqrt(be.diff_sumsq(be.forward(poses, x, tmp), ax) / be.dot(ax, ax)) < 1e-6
+        be.ctx.set_option("fwd_variant", 3)
+        be.ctx.set_option("adj_variant", 1)
+        assert np.sqrt(be.diff_sumsq(be.adjoint(poses, y, tmp2), aty) / be.dot(aty, aty)) < 1e-5
+        be.ctx.set_option("adj_variant", 2)
+        # x-slab adjoint: the slabs add up to the whole
+        n_xt, _ = be.xslab_info()
+        be.fill(tmp2, 0.0)
+        for a, b in ((0, n_xt // 3), (n_xt // 3, n_xt - 5), (n_xt - 5, n_xt)):
+            be.adjoint_xslab(poses, y, tmp2, a, b)
+        assert np.sqrt(be.diff_sumsq(tmp2, aty) / be.dot(aty, aty)) < 1e-6
+    # the flat kernels against the general tile kernels on the same untilted poses
+    be.forward(flat, x, ax); be.adjoint(flat, y, aty)
+    be.ctx.set_option("tile_flat", 0)
+    assert np.sqrt(be.diff_sumsq(be.forward(flat, x, tmp), ax) / be.dot(ax, ax)) < 1e-6
+    assert np.sqrt(be.diff_sumsq(be.adjoint(flat, y, tmp2), aty) / be.dot(aty, aty)) < 1e-5
+    be.ctx.set_option("tile_flat", 1)

@@ -178,6 +178,10 @@ __global__ __launch_bounds__(256) void k_fwd_v2(const ProjC *__restrict__ pcs, c
     const int J1 = __builtin_amdgcn_readfirstlane(wave_max_i32(nonempty ? r.j1 : 0));
     const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
     const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;
+    // dword gathers on purpose (a wave-wide dwordx2 costs 3.5x a dword in the L1 pipeline, tools/gather_bench.hip): the z + 1
+    // bases carry an offset the compiler cannot see through, so it does not fuse the corner pairs
+    int four;
+    asm volatile("s_mov_b32 %0, 4" : "=s"(four));
     double total = 0.0;
     for (int jb = J0; jb < J1; jb += TOMO_JB) {
         int ia[3];
@@ -191,6 +195,7 @@ __global__ __launch_bounds__(256) void k_fwd_v2(const ProjC *__restrict__ pcs, c
         const char *sb01 = sb00 + sy4;
         const char *sb10 = sb00 + sx4;
         const char *sb11 = sb10 + sy4;
+        const char *sc00 = sb00 + four, *sc01 = sb01 + four, *sc10 = sb10 + four, *sc11 = sb11 + four;
         const uint32_t off0 = (uint32_t)(delta - m) * 4u;
         const int lo = max(r.j0, jb) - jb, hi = min(r.j1, jb + TOMO_JB) - jb;
         float acc = 0.f;
@@ -199,10 +204,10 @@ __global__ __launch_bounds__(256) void k_fwd_v2(const ProjC *__restrict__ pcs, c
             const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
             const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
             const uint32_t vo = off0 + __umul24((uint32_t)(int)fx, sx4) + __umul24((uint32_t)(int)fy, sy4) + ((uint32_t)(int)fz << 2);
-            const float v000 = *(const float *)(sb00 + vo), v001 = *(const float *)(sb00 + vo + 4);
-            const float v010 = *(const float *)(sb01 + vo), v011 = *(const float *)(sb01 + vo + 4);
-            const float v100 = *(const float *)(sb10 + vo), v101 = *(const float *)(sb10 + vo + 4);
-            const float v110 = *(const float *)(sb11 + vo), v111 = *(const float *)(sb11 + vo + 4);
+            const float v000 = *(const float *)(sb00 + vo), v001 = *(const float *)(sc00 + vo);
+            const float v010 = *(const float *)(sb01 + vo), v011 = *(const float *)(sc01 + vo);
+            const float v100 = *(const float *)(sb10 + vo), v101 = *(const float *)(sc10 + vo);
+            const float v110 = *(const float *)(sb11 + vo), v111 = *(const float *)(sc11 + vo);
             acc += trilerp(v000, v001, v010, v011, v100, v101, v110, v111, x - fx, y - fy, z - fz);
         }
         total += (double)acc;
