@@ -220,21 +220,30 @@ def align_rate(comm, ctx, rank, world, N=512, n_proj=720, passes=3):
     vol = be.phantom(be.empty(N ** 3), (N, N, N), SHEPP_LOGAN)
     truth = _lib.poses_array(phi[mine], alpha[mine], beta[mine], xyz[mine], np.zeros(3))
     b = be.forward(truth, vol, be.empty(mine.size * N * N))
-    start = _lib.poses_array(phi[mine], 0 * alpha[mine], 0 * beta[mine], 0 * xyz[mine], np.zeros(3))   # evaluate at the unaligned start
-    be.cost_grad(start, vol, b)
-    ctx.sync()
-    comm.barrier()
-    t0 = time.perf_counter()
-    for _ in range(passes):
-        cost, g6 = be.cost_grad(start, vol, b)
-    ctx.sync()
-    comm.barrier()
-    dt = comm.allreduce_max(time.perf_counter() - t0)
-    rate = passes * n_proj / dt
+    # An optimiser starts at the nominal (untilted) poses and ends near the true (tilted) ones; the kernels are slower on
+    # tilted poses, so the headline rate is taken at poses half a degree / one pixel away from the truth and the rate at
+    # the untilted start is reported beside it.
+    near = _lib.poses_array(phi[mine], alpha[mine] + np.deg2rad(0.5), beta[mine] - np.deg2rad(0.5), xyz[mine] + np.array([1.0, 0.0, -1.0]), np.zeros(3))
+    start = _lib.poses_array(phi[mine], 0 * alpha[mine], 0 * beta[mine], 0 * xyz[mine], np.zeros(3))
+    rates = {}
+    for tag, poses in (("near_truth", near), ("start", start)):
+        be.cost_grad(poses, vol, b)
+        ctx.sync()
+        comm.barrier()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            cost, g6 = be.cost_grad(poses, vol, b)
+        ctx.sync()
+        comm.barrier()
+        dt = comm.allreduce_max(time.perf_counter() - t0)
+        rates[tag] = (passes * n_proj / dt, float(cost[0]))
+    rate = rates["near_truth"][0]
     alg = 4.0 * N ** 3 + 4.0 * N * N + 28.0                      # fused form, BASELINE.md section 3
-    return {"evals_per_sec": round(rate, 1), "unit": "evals/s", "config": "%d^3 volume, %d projections, +-2 deg / +-5 px, fused cost+6-DoF gradient"
-            % (N, n_proj), "alg_GBps": round(rate * alg / 1e9, 1), "frac_of_hbm_peak": round(rate * alg / 1e9 / HBM_PEAK_GBS, 4),
-            "projections_per_launch": int(mine.size), "cost_first": float(cost[0])}
+    return {"evals_per_sec": round(rate, 1), "unit": "evals/s", "config": "%d^3 volume, %d projections simulated with +-2 deg / +-5 px pose "
+            "errors, fused cost+6-DoF gradient evaluated 0.5 deg / 1 px away from the true poses" % (N, n_proj),
+            "alg_GBps": round(rate * alg / 1e9, 1), "frac_of_hbm_peak": round(rate * alg / 1e9 / HBM_PEAK_GBS, 4),
+            "evals_per_sec_at_untilted_start": round(rates["start"][0], 1),
+            "projections_per_launch": int(mine.size), "cost_first": rates["near_truth"][1], "cost_first_at_start": rates["start"][1]}
 
 
 def cpu_baseline(be, d_true, N, n_proj, phi):

@@ -86,9 +86,13 @@ TOMO_API int tomo_sync(tomo_ctx *ctx);
 /* Integer knobs; unknown keys are TOMO_ERR_ARG.
  *   "fwd_variant" 1 ray-driven (plain), 2 ray-driven (SGPR block base), 3 LDS tile kernels (default)
  *   "adj_variant" 1 global float atomics, 2 LDS tile kernels with fixed-point accumulation (default)
- *   "grad_variant" 1 plain kernel (per-lane 64-bit addressing, corner pairs as dwordx2 gathers), 2 (default) wave-uniform block
- *                  base + 32-bit lane offsets, eight dword gathers, two samples in flight, pair-packed lerps and a cache-aware
- *                  block order -- same sums, 1.3x faster at 512^3 x 720                (tomo_proj_grad / tomo_cost_grad)
+ *   "grad_variant" kernels behind tomo_proj_grad / tomo_cost_grad(_rows); all give the same sums:
+ *                  1 plain (per-lane 64-bit addressing, corner pairs as dwordx2 gathers);
+ *                  2 wave-uniform block base + 32-bit lane offsets, eight dword gathers, two samples in flight, pair-packed
+ *                    lerps, cache-aware block order -- fastest for near-untilted poses;
+ *                  3 as 2 with four gathers per sample: the upper-z corners come from the neighbouring lane (DPP wave
+ *                    shift) -- nearly insensitive to tilt, fastest beyond |alpha| + |beta| ~ 1 deg;
+ *                  4 (default) each pose of a call takes 2 or 3 by its tilt (two launches)
  *   "tile_flat"   1 (default): untilted projections (alpha = beta = 0, detector-z pitch 1) take the flat tile kernels
  *   "reuse_staged_volume" 1: the caller vouches that the volume passed to tomo_proj_grad / tomo_cost_grad / the ray-driven
  *                 forward has not changed since the previous such call with the same pointer, so its zero-padded staging
@@ -146,6 +150,12 @@ TOMO_API int tomo_proj_grad(tomo_ctx *ctx, const double *h_pose, const float *d_
  *   d_b [n][n_det]; h_cost [n], h_grad6 [n][6] (host, double).  d_resid may be NULL or [n][n_det]. */
 TOMO_API int tomo_cost_grad(tomo_ctx *ctx, const double *h_poses, int n, const float *d_vol, const float *d_b,
                    double *h_cost, double *h_grad6, float *d_resid);
+/* Same, with the measured projections picked from a device-resident table instead of being packed per call: pose i is
+ *   compared with row h_rows[i] of d_b_table [n_rows_total][n_det] (h_rows NULL = identity).  An alignment loop keeps all
+ *   measured projections in HBM and evaluates a changing subset each round (examples/align_rigid.py:40-52 evaluates one
+ *   projection at a time); outputs are indexed by i.  d_resid may be NULL or [n][n_det]. */
+TOMO_API int tomo_cost_grad_rows(tomo_ctx *ctx, const double *h_poses, int n, const float *d_vol, const float *d_b_table,
+                   const int32_t *h_rows, int n_rows_total, double *h_cost, double *h_grad6, float *d_resid);
 
 /* tomo_triplets: COO triplets of one projection with the emission order and values of
  *   src/ray_wt_grad.f90:1-92 trilinear_ray_sparse (ray-major, sample, corner; float64 weights).

@@ -82,13 +82,14 @@ class OracleBackend(object):
         proj_out.a[:] = p
         grad_out.a[:] = g.ravel()
 
-    def cost_grad(self, poses, vol, b, resid=None):
+    def cost_grad(self, poses, vol, b, resid=None, rows=None):
         n = poses.shape[0]
         cost, g6 = np.zeros(n), np.zeros((n, 6))
+        table = b.a.reshape(-1, self.n_det)
         for i in range(n):
             self.calls["cost_grad"] += 1
             p, g = orc.projection_gradient(self.og, vol.a, poses[i, 1], poses[i, 2], poses[i, 0], poses[i, 3:6], np.array([poses[i, 6], 0, 0]))
-            res = b.a.reshape(n, -1)[i].astype(np.float64) - p
+            res = table[i if rows is None else int(rows[i])].astype(np.float64) - p
             cost[i] = 0.5 * np.dot(res, res)
             g6[i] = np.dot(-g.astype(np.float64), res)
         return cost, g6

@@ -102,7 +102,7 @@ def test_voxel_mask_step_and_detector_shape(PM, orc):
     assert rel_max(A.T.dot(y), ref.T.dot(y)) < TOL
 
 
-@pytest.mark.parametrize("grad_variant", [1, 2])
+@pytest.mark.parametrize("grad_variant", [1, 2, 3, 4])
 def test_projection_gradient_vs_reference_golden(PM, shepp32, grad_variant):
     g = golden("g3_proj_grad")
     geo, _ = geo_pair(1, 32)
@@ -170,6 +170,12 @@ def test_cost_grad_fused_vs_oracle(PM, orc, shepp32):
     assert np.max(np.abs(g6 - np.array(want_g)) / np.array(scale_g)) < TOL
     r = resid.download().reshape(n, -1)
     assert rel_max(r[0], b[0] - orc.projection_gradient(og, shepp32, g["alpha"][0], g["beta"][0], g["phi"][0], g["xyz"][0], g["cor"][0])[0]) < 1e-4
+    # row-indexed form (tomo_cost_grad_rows): a subset of the poses against their rows of the resident table
+    pick = np.array([2, 0])
+    c2, g2 = be.cost_grad(np.ascontiguousarray(poses[pick]), be.upload(shepp32), be.upload(b), rows=pick)
+    assert np.allclose(c2, cost[pick], rtol=1e-12) and np.allclose(g2, g6[pick], rtol=1e-9, atol=1e-9)
+    with pytest.raises(_lib.TomoError):
+        be.cost_grad(np.ascontiguousarray(poses[:1]), be.upload(shepp32), be.upload(b), rows=np.array([3]))
 
 
 @pytest.mark.parametrize("shape,ndet,step,n_proj", [((20, 24, 70), (20, 70), 1.0, 3),     # ragged, nz > 64, not multiple of 64
@@ -379,8 +385,9 @@ def test_alignment_gradient_at_128_vs_oracle(PM, orc):
 
 @pytest.mark.parametrize("shape,ndet", [((24, 20, 70), (24, 70)), ((16, 16, 5), (20, 9)), ((48, 40, 130), (50, 140))])
 def test_gradient_kernel_variants_agree_on_odd_shapes(PM, orc, shape, ndet):
-    """grad_variant 2 (four gathers + neighbour-lane shift) vs 1 (eight gathers) vs the oracle, incl. large tilts where the
-    neighbour lane often does not line up, rays that leave the volume, and detector rows shorter than a wave."""
+    """grad_variant 1 (plain), 2 (dword gathers, packed lerps) and 3 (four gathers + neighbour-lane DPP shift) against the
+    oracle and each other, incl. large tilts where the neighbour lane often does not line up, rays that leave the volume,
+    and detector rows shorter than a wave."""
     from tomography_alignment_amd import _lib
     rng = np.random.default_rng(31)
     geo, og = geo_pair(1, None, ndet=ndet, shape=shape)
@@ -390,7 +397,7 @@ def test_gradient_kernel_variants_agree_on_odd_shapes(PM, orc, shape, ndet):
         t = np.array(t)
         want_p, want_g = orc.projection_gradient(og, x, alpha, beta, phi, t, np.array([0.7, 0., 0.]), precision=np.float64)
         out = {}
-        for v in (1, 2):
+        for v in (1, 2, 3):
             P = PM(geo, precision=np.float64)
             P.backend.ctx.set_option("grad_variant", v)
             out[v] = P.projection_gradient(x, alpha, beta, phi, t, np.array([0.7, 0., 0.]))
@@ -398,6 +405,7 @@ def test_gradient_kernel_variants_agree_on_odd_shapes(PM, orc, shape, ndet):
             for k in range(6):
                 assert rel_max(out[v][1][k], want_g[k]) < TOL, (v, k)
         assert rel_max(out[2][0], out[1][0]) < 5e-6 and rel_max(out[2][1], out[1][1]) < 5e-6    # float32 lerps in another order
+        assert rel_max(out[3][0], out[2][0]) < 1e-6 and rel_max(out[3][1], out[2][1]) < 1e-6    # same arithmetic, other data path
 
 
 @pytest.mark.parametrize("ndet", [(384, 340), (402, 350)])      # 96 ix groups (XCD swizzle) / 101 (plain)
@@ -433,7 +441,7 @@ def test_cost_grad_cache_ordered_grid_vs_oracle(PM, orc, ndet):
     be = P.backend
     vol, bd, resid = be.upload(x), be.upload(b), be.empty(n * n_det)
     out = {}
-    for v in (2, 1):
+    for v in (4, 3, 2, 1):                  # 4 = per-pose choice: poses 0, 1 (tilted) -> kernel 3, pose 2 -> kernel 2, two launches
         be.ctx.set_option("grad_variant", v)
         cost, g6 = be.cost_grad(poses, vol, bd, resid)
         out[v] = (cost.copy(), g6.copy())

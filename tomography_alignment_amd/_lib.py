@@ -55,6 +55,8 @@ SIGNATURES = {
     "tomo_backproject_voxel": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp]),
     "tomo_proj_grad": (ctypes.c_int, [_c_vp, _c_dp, _c_vp, _c_vp, _c_vp, ctypes.c_int]),
     "tomo_cost_grad": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp, _c_dp, _c_dp, _c_vp]),
+    "tomo_cost_grad_rows": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, _c_dp, _c_dp,
+                                           _c_vp]),
     "tomo_triplets": (ctypes.c_int, [_c_vp, _c_dp, _c_i64, _c_vp, _c_vp, _c_vp, ctypes.POINTER(_c_i64)]),
     "tomo_vox_splat": (ctypes.c_int, [_c_vp, _c_dp, _c_dp, _c_vp, _c_vp, _c_vp]),
     "tomo_vox_triplets": (ctypes.c_int, [_c_vp, _c_dp, _c_dp, _c_vp, _c_vp]),

@@ -12,7 +12,9 @@ Multi-GPU: projections are independent -- rank r aligns np.array_spl
 replicated volume and no collective inside the optimiser; the 4 recovered parameters per projection are gathered
 once at the end (an all-reduce of a zero-padded table).
 """
+import sys
 import threading
+import time
 
 import numpy as np
 from scipy import optimize
@@ -35,13 +37,12 @@ class BatchEvaluator(object):
         self.vol = rec if backend.is_buffer(rec) else backend.upload(np.asarray(rec, np.float32).ravel())
         b = np.asarray(projections, np.float32)
         self.n = b.shape[0]
-        self.b_host = b.reshape(self.n, -1)
-        self._b_all = backend.upload(self.b_host)
+        self._b_all = backend.upload(b.reshape(self.n, -1))
         self.cor = np.zeros(self.n) if cor_shift is None else np.asarray(cor_shift, np.float64).reshape(self.n, -1)[:, 0]
-        self._gather = None
         self._staged = False
         self.n_launch = 0
         self.n_eval = 0
+        self.t_eval = 0.0       # seconds inside the evaluation calls (kernel + staging), for reports
 
     def evaluate(self, idx, poses6):
         """idx: projection indices (m,), poses6: (m,6) rows (phi, alpha, beta, tx, ty, tz) -> cost[m], grad6[m,6]."""
@@ -50,75 +51,96 @@ class BatchEvaluator(object):
         poses = np.zeros((m, _lib.POSE_STRIDE), np.float64)
         poses[:, :6] = poses6
         poses[:, 6] = self.cor[idx]
-        n_det = self.be.n_det
-        if m == self.n and np.array_equal(idx, np.arange(self.n)):
-            b = self._b_all
-        else:
-            if self._gather is None or self._gather.size < m * n_det:
-                self._gather = self.be.empty(max(m, 16) * n_det)
-            b = self._gather.view(0, m * n_det)
-            b.upload(self.b_host[idx])            # host-side gather of the active rows (few MB per round)
         self.n_launch += 1
         self.n_eval += m
-        ctx = getattr(self.be, "ctx", None)
-        if ctx is not None:                     # self.vol is pinned for the evaluator's lifetime: stage it once
-            ctx.set_option("reuse_staged_volume", 1 if self._staged else 0)
-        try:
-            out = self.be.cost_grad(np.ascontiguousarray(poses), self.vol, b)
+        t0 = time.perf_counter()
+        out = self.be.cost_grad(np.ascontiguousarray(poses), self.vol, self._b_all, rows=idx)   # measured rows stay in HBM
+        if not self._staged:                    # self.vol is pinned until close(): its zero-padded copy is staged once
             self._staged = True
-        finally:
+            ctx = getattr(self.be, "ctx", None)
             if ctx is not None:
-                ctx.set_option("reuse_staged_volume", 0)
+                ctx.set_option("reuse_staged_volume", 1)
+        self.t_eval += time.perf_counter() - t0
         return out
+
+    def close(self):
+        """Give the context back: the next caller's volume is staged afresh."""
+        ctx = getattr(self.be, "ctx", None)
+        if self._staged and ctx is not None:
+            ctx.set_option("reuse_staged_volume", 0)
+        self._staged = False
 
 
 class _Scheduler(object):
-    """Collects one pending request per live worker, evaluates them in one batch, releases the workers."""
+    """Batches the workers' evaluation requests.  A launch goes out as soon as at least half of the live workers are
+    waiting (all of them once few are left), so the Python side of scipy's iterations for one half overlaps the kernel
+    of the other half (ctypes drops the GIL during the call).  Every worker sleeps on its own Event: a request wakes
+    the scheduler only, a finished batch wakes exactly its workers."""
 
-    def __init__(self, evaluator, n_workers):
+    def __init__(self, evaluator, small=8):
         self.ev = evaluator
-        self.cv = threading.Condition()
-        self.live = n_workers
+        self.lock = threading.Lock()
+        self.wake = threading.Condition(self.lock)        # the scheduler alone waits here
+        self.live = 0
         self.pending = {}
         self.results = {}
+        self.events = {}
         self.error = None
+        self.small = small
+
+    def enter(self, i):
+        with self.lock:
+            self.live += 1
+            self.events[i] = threading.Event()
+
+    def leave(self, i):
+        with self.lock:
+            self.live -= 1
+            del self.events[i]
+            self.wake.notify()
+
+    def _ready(self):
+        n = len(self.pending)
+        return n > 0 and (n == self.live or (self.live > self.small and 2 * n >= self.live))
 
     def request(self, i, pose6):
-        with self.cv:
+        ev = self.events[i]
+        with self.lock:
+            if self.error is not None:
+                raise self.error
             self.pending[i] = pose6
-            self.cv.notify_all()
-            while i not in self.results and self.error is None:
-                self.cv.wait()
+            if self._ready():
+                self.wake.notify()
+        ev.wait()
+        ev.clear()
+        with self.lock:
             if self.error is not None:
                 raise self.error
             return self.results.pop(i)
 
-    def done(self):
-        with self.cv:
-            self.live -= 1
-            self.cv.notify_all()
-
-    def run(self):
+    def run(self, finished):
+        """Serve requests until `finished()` (called under the lock) says no worker is left or to come."""
         while True:
-            with self.cv:
-                while self.live > 0 and len(self.pending) < self.live:
-                    self.cv.wait()
-                if self.live == 0 and not self.pending:
-                    return
+            with self.lock:
+                while not self._ready():
+                    if finished() and self.live == 0:
+                        return
+                    self.wake.wait(0.05)
                 idx = sorted(self.pending)
                 poses = np.array([self.pending[i] for i in idx])
                 self.pending.clear()
             try:
                 cost, g6 = self.ev.evaluate(idx, poses)
             except Exception as e:                      # release the workers, re-raise in the caller
-                with self.cv:
+                with self.lock:
                     self.error = e
-                    self.cv.notify_all()
+                    for ev in self.events.values():
+                        ev.set()
                 raise
-            with self.cv:
+            with self.lock:
                 for k, i in enumerate(idx):
                     self.results[i] = (float(cost[k]), g6[k].copy())
-                self.cv.notify_all()
+                    self.events[i].set()
 
 
 def align_projections(backend, rec, projections, phi, letters="xzab", x0=None, angles0=None, xyz0=None, cor_shift=None,
@@ -151,34 +173,59 @@ def align_projections(backend, rec, projections, phi, letters="xzab", x0=None, a
     opts = {"disp": False}
     opts.update(options or {})
 
-    for c0 in range(0, indices.size, max_threads):
-        chunk = indices[c0:c0 + max_threads]
-        sched = _Scheduler(ev, chunk.size)
-        errors = []
+    # a rolling pool: at most max_threads optimisers are live; when one converges the next projection starts, so the
+    # batches stay full until the very end instead of draining once per chunk
+    sched = _Scheduler(ev)
+    errors = []
+    slots = threading.Semaphore(max_threads)
+    state = {"started": 0}
 
-        def work(i):
-            try:
-                def fun(p):
-                    pose = base[i].copy()
-                    pose[cols] += p
-                    cost, g6 = sched.request(i, pose)
-                    return cost, g6[rows] * scale
-                res = optimize.minimize(fun, x0[i], jac=True, method="L-BFGS-B", bounds=bounds, options=opts)
-                out_x[i], out_f[i], out_n[i] = res.x, res.fun, res.nfev
-            except Exception as e:      # noqa: BLE001
-                errors.append(e)
-            finally:
-                sched.done()
+    def work(i):
+        try:
+            def fun(p):
+                pose = base[i].copy()
+                pose[cols] += p
+                cost, g6 = sched.request(i, pose)
+                return cost, g6[rows] * scale
+            res = optimize.minimize(fun, x0[i], jac=True, method="L-BFGS-B", bounds=bounds, options=opts)
+            out_x[i], out_f[i], out_n[i] = res.x, res.fun, res.nfev
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+        finally:
+            sched.leave(i)
+            slots.release()
 
-        threads = [threading.Thread(target=work, args=(int(i),), daemon=True) for i in chunk]
-        for t in threads:
-            t.start()
-        sched.run()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
-    return {"x": out_x, "fun": out_f, "nfev": out_n, "n_launch": ev.n_launch, "n_eval": ev.n_eval}
+    def spawn():
+        first = [int(i) for i in indices[:max_threads]]
+        for i in first:                                # the first pool is registered as a whole, so that the first launch
+            slots.acquire()                            # waits for all of it instead of firing on the first arrival
+            sched.enter(i)
+        for i in first:
+            threading.Thread(target=work, args=(i,), daemon=True).start()
+        for i in indices[max_threads:]:
+            slots.acquire()
+            if errors:
+                slots.release()
+                break
+            sched.enter(int(i))
+            threading.Thread(target=work, args=(int(i),), daemon=True).start()
+        with sched.lock:
+            state["started"] = -1                      # nobody left to start
+            sched.wake.notify()
+
+    spawner = threading.Thread(target=spawn, daemon=True)
+    switch = sys.getswitchinterval()
+    sys.setswitchinterval(min(switch, 5e-4))           # hundreds of short-running threads: hand the GIL over promptly
+    spawner.start()
+    try:
+        sched.run(lambda: state["started"] == -1)
+    finally:
+        spawner.join()
+        ev.close()
+        sys.setswitchinterval(switch)
+    if errors:
+        raise errors[0]
+    return {"x": out_x, "fun": out_f, "nfev": out_n, "n_launch": ev.n_launch, "n_eval": ev.n_eval, "t_eval": ev.t_eval}
 
 
 def align_projections_sharded(comm, backend, rec, projections, phi, **kw):

@@ -94,14 +94,25 @@ class HipBackend(object):
         self._geom()
         self.ctx.check(self.lib.tomo_proj_grad(self.ctx.handle, _lib.dptr(pose), vol.ptr, proj_out.ptr, grad_out.ptr, row_order))
 
-    def cost_grad(self, poses, vol, b, resid=None):
-        """-> (cost[n], grad6[n,6]) float64 on the host (fused residual / cost / gradient reduction)."""
+    def cost_grad(self, poses, vol, b, resid=None, rows=None):
+        """-> (cost[n], grad6[n,6]) float64 on the host (fused residual / cost / gradient reduction).  With `rows`, pose i
+        is compared with row rows[i] of the device-resident table `b` ([n_rows][n_det]) instead of row i."""
         self._geom()
         n = poses.shape[0]
         cost = np.zeros(n, np.float64)
         g6 = np.zeros((n, 6), np.float64)
-        self.ctx.check(self.lib.tomo_cost_grad(self.ctx.handle, _lib.dptr(poses), n, vol.ptr, b.ptr, _lib.dptr(cost), _lib.dptr(g6),
-                                               resid.ptr if resid is not None else None))
+        if rows is None:
+            if b.size < n * self.n_det:
+                raise ValueError("cost_grad: measured projections smaller than n * n_det")
+            self.ctx.check(self.lib.tomo_cost_grad(self.ctx.handle, _lib.dptr(poses), n, vol.ptr, b.ptr, _lib.dptr(cost), _lib.dptr(g6),
+                                                   resid.ptr if resid is not None else None))
+        else:
+            rows = np.ascontiguousarray(rows, np.int32)
+            if rows.size != n or b.size % self.n_det:
+                raise ValueError("cost_grad: rows must have one entry per pose and b must be whole rows")
+            self.ctx.check(self.lib.tomo_cost_grad_rows(self.ctx.handle, _lib.dptr(poses), n, vol.ptr, b.ptr,
+                                                        rows.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), b.size // self.n_det,
+                                                        _lib.dptr(cost), _lib.dptr(g6), resid.ptr if resid is not None else None))
         return cost, g6
 
     def triplets(self, pose):

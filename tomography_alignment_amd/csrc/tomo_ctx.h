@@ -42,7 +42,7 @@ struct tomo_ctx {
     // options
     int fwd_variant = 3;      // 1 ray-driven plain, 2 ray-driven SGPR-base, 3 LDS tile (default)
     int adj_variant = 2;      // 1 global float atomics, 2 LDS tile fixed-point (default)
-    int grad_variant = 2;     // 1 per-lane 64-bit addressing + dwordx2 pair gathers, 2 SGPR block base, dword gathers, packed lerps (default)
+    int grad_variant = 4;     // 1 plain, 2 eight dword gathers + packed lerps, 3 four gathers + DPP neighbour shift, 4 (default) 2 or 3 per pose by tilt
     int tile_flat = 1;      // 1: untilted projections take the flat tile kernels
     // timing / profiling
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

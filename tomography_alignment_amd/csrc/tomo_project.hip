@@ -804,8 +804,8 @@ __global__ __launch_bounds__(256) void k_proj_grad(const ProjC *__restrict__ pcs
         double part[7] = {0, 0, 0, 0, 0, 0, 0};
         if (valid) {
             const float pv = (float)val;                                  // projection_operators.py:119 cast
-            const double res = (double)(bvec[(size_t)ip * n_det + ray] - pv);   // alignment_functions.py:23
-            if (resid) resid[(size_t)ip * n_det + ray] = (float)res;
+            const double res = (double)(bvec[(size_t)gc.b_row * n_det + ray] - pv);   // alignment_functions.py:23
+            if (resid) resid[(size_t)gc.slot * n_det + ray] = (float)res;
             part[0] = 0.5 * res * res;                                    // :124
 #pragma unroll
             for (int k = 0; k < 6; ++k) part[1 + k] = -(double)(float)gk[k] * res;   // :35,146
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(256) void k_proj_grad(const ProjC *__restrict__ pcs
         __syncthreads();
         if (threadIdx.x < 7) {
             const int k = threadIdx.x;
-            atomicAdd(&red[(size_t)ip * 7 + k], sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k]);
+            atomicAdd(&red[(size_t)gc.slot * 7 + k], sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k]);
         }
     }
 }
@@ -987,8 +987,8 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
         double part[7] = {0, 0, 0, 0, 0, 0, 0};
         if (valid) {
             const float pv = (float)val;
-            const double res = (double)(bvec[(size_t)ip * n_det + ray] - pv);
-            if (resid) resid[(size_t)ip * n_det + ray] = (float)res;
+            const double res = (double)(bvec[(size_t)gc.b_row * n_det + ray] - pv);
+            if (resid) resid[(size_t)gc.slot * n_det + ray] = (float)res;
             part[0] = 0.5 * res * res;
 #pragma unroll
             for (int k = 0; k < 6; ++k) part[1 + k] = -(double)(float)gk[k] * res;
@@ -1002,7 +1002,202 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
         __syncthreads();
         if (threadIdx.x < 7) {
             const int k = threadIdx.x;
-            atomicAdd(&red[(size_t)ip * 7 + k], sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k]);
+            atomicAdd(&red[(size_t)gc.slot * 7 + k], sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// projection + gradient, variant 3: four gathers per sample instead of eight.  Lanes run along detector-z, so lane l's
+// upper-z corners are normally lane l+1's lower-z corners: every lane gathers its four lower-z corners and receives the upper
+// ones from its neighbour with a DPP wave shift (v_mov_b32_dpp wave_shl:1 -- a full-rate VALU op on gfx950, tools/dpp_check.hip);
+// where the neighbour's address is not mine + 4 (tilt-induced row steps, lane 63) the lane loads them itself.  That decision
+// needs only the ADDRESSES, so the fallback loads are issued together with the main ones.
+// For the shift to read live registers the sample loop is wave-uniform over the union of the lanes' ranges; a lane outside
+// its own range still loads -- at its own ray's nearest in-range sample (always inside the padded volume), or, with no sample
+// in the block at all, at the first sample of the first lane that has one -- and its contribution is masked.  Since every
+// lane's values really are the volume at the address it advertises, "neighbour address == mine + 4" is all a lane must check.
+// The gathers are what bounds the gradient kernels under tilt (TA busy 100 %): time grows linearly with the tilt because
+// a 16-lane group then straddles more volume rows; halving the gathers halves that term.
+// ------------------------------------------------------------------------------------------------
+// lane l <- lane l + 1; lane 63 <- 0 (bound_ctrl: no `old` register to initialise)
+__device__ __forceinline__ int dpp_shl1_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
+__device__ __forceinline__ float dpp_shl1_f(float v) { return __builtin_bit_cast(float, dpp_shl1_i(__builtin_bit_cast(int, v))); }
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ pcs, const GradC *__restrict__ gcs,
+                                                      const float *__restrict__ vp, float *__restrict__ proj,
+                                                      float *__restrict__ grad, const float *__restrict__ bvec,
+                                                      float *__restrict__ resid, double *__restrict__ red, TomoGeomC g,
+                                                      int row_order)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int ix, ip, iz;
+    if (row_order & 16) {                              // cache-ordered grid, see k_proj_grad_v2
+        const int nxg = gridDim.x;
+        const int xg = ((nxg & 7) == 0) ? ((int)(blockIdx.x & 7) * (nxg >> 3) + (int)(blockIdx.x >> 3)) : (int)blockIdx.x;
+        ix = xg * 4 + wv, ip = blockIdx.y, iz = blockIdx.z * 64 + lane;
+    } else {
+        ix = blockIdx.y * 4 + wv, ip = blockIdx.z, iz = blockIdx.x * 64 + lane;
+    }
+    row_order &= 15;
+    const bool valid = (ix < g.ndx) && (iz < g.ndz);
+    const int ixc = min(ix, g.ndx - 1);
+    if (iz >= g.ndz) iz = g.ndz - 1;
+    const ProjC &c = pcs[ip];
+    const GradC &gc = gcs[ip];
+    RayCtx r;
+    ray_setup(c, g, ixc, iz, valid, r);
+    const bool nonempty = r.j1 > r.j0;
+    const int J0 = __builtin_amdgcn_readfirstlane(wave_min_i32(nonempty ? r.j0 : INT_MAX));
+    const int J1 = __builtin_amdgcn_readfirstlane(wave_max_i32(nonempty ? r.j1 : 0));
+    const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
+    const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;
+    const float sfs = (float)(g.step / c.rlen);
+    double val = 0.0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
+    for (int jb = J0; jb < J1; jb += TOMO_JB) {
+        int ia[3];
+        float f0[3];
+        tomo_block_anchor(r.b, r.d, jb, ia, f0);
+        const int64_t lin = ((int64_t)(ia[0] + TOMO_HALO) * g.nyp + (ia[1] + TOMO_HALO)) * g.nzp + (ia[2] + TOMO_HALO);
+        const int64_t lin0 = readfirstlane_i64(lin);
+        const int delta = (int)(lin - lin0);
+        const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(delta));
+        const char *sb00 = (const char *)(vp + (lin0 + m));
+        const char *sb01 = sb00 + sy4;
+        const char *sb10 = sb00 + sx4;
+        const char *sb11 = sb10 + sy4;
+        const uint32_t off0 = (uint32_t)(delta - m) * 4u;
+        const int lo = max(r.j0, jb) - jb, hi = min(r.j1, jb + TOMO_JB) - jb;      // this lane's samples of the block
+        const bool has = hi > lo;
+        const unsigned long long hm = __ballot(has);
+        if (hm == 0ull) continue;                                                  // wave-uniform
+        const int LO = __builtin_amdgcn_readfirstlane(wave_min_i32(has ? lo : INT_MAX));
+        const int HI = __builtin_amdgcn_readfirstlane(wave_max_i32(has ? hi : 0));
+        // a lane with no sample in this block gathers where the first lane that has one takes its first sample
+        uint32_t borrow;
+        {
+            const float t = (float)lo;
+            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
+            const uint32_t mine = off0 + __umul24((uint32_t)(int)floorf(x), sx4) + __umul24((uint32_t)(int)floorf(y), sy4) + ((uint32_t)(int)floorf(z) << 2);
+            borrow = (uint32_t)__builtin_amdgcn_readlane((int)mine, __builtin_ctzll(hm));
+        }
+        const int lo_c = has ? lo : 0, hi_c = has ? hi - 1 : 0;
+        const float sfb = (float)jb * sfs;
+        float av = 0.f;
+        f32x2 a0xy = {0.f, 0.f}, a1xy = {0.f, 0.f}, az = {0.f, 0.f};              // (S0x, S0y), (S1x, S1y), (S0z, S1z)
+        // issue: addresses, the four gathers, and -- decided from the addresses alone -- the fallback gathers.
+        // (Macros over plain scalars on purpose: a struct passed to helper lambdas was promoted to an LDS alloca, which put
+        // a store of every loaded value -- hence a vmcnt(0) wait -- between the two samples' loads.)
+#define GS_DECL(S) float S##v000, S##v010, S##v100, S##v110, S##f001, S##f011, S##f101, S##f111, S##wx, S##wy, S##wz, S##t; /* f*: set and read only where fb */ \
+                   bool S##act, S##fb
+#define GS_ISSUE(S, JJ)                                                                                                            \
+    {                                                                                                                              \
+        const int jc = min(max((JJ), lo_c), hi_c); /* own ray's nearest in-range sample */                                         \
+        S##act = has && jc == (JJ);                                                                                                \
+        S##t = (float)jc;                                                                                                          \
+        const float x = fmaf(S##t, dxf, f0[0]), y = fmaf(S##t, dyf, f0[1]), z = fmaf(S##t, dzf, f0[2]);                            \
+        const float fx = floorf(x), fy = floorf(y), fz = floorf(z);                                                                \
+        S##wx = x - fx; S##wy = y - fy; S##wz = z - fz;                                                                            \
+        const uint32_t vo_own = off0 + __umul24((uint32_t)(int)fx, sx4) + __umul24((uint32_t)(int)fy, sy4) + ((uint32_t)(int)fz << 2); \
+        const uint32_t vo = has ? vo_own : borrow;                                                                                 \
+        S##v000 = *(const float *)(sb00 + vo); S##v010 = *(const float *)(sb01 + vo);                                              \
+        S##v100 = *(const float *)(sb10 + vo); S##v110 = *(const float *)(sb11 + vo);                                              \
+        const uint32_t nb = (uint32_t)dpp_shl1_i((int)vo); /* lane 63 receives 0: never vo + 4 */                                 \
+        const uint32_t vo4 = vo + 4u;                                                                                              \
+        S##fb = S##act && nb != vo4;                                                                                               \
+        if (S##fb) { /* my upper-z cell is not the neighbour's lower-z cell */                                                     \
+            S##f001 = *(const float *)(sb00 + vo4); S##f011 = *(const float *)(sb01 + vo4);                                        \
+            S##f101 = *(const float *)(sb10 + vo4); S##f111 = *(const float *)(sb11 + vo4);                                        \
+        }                                                                                                                          \
+    }
+        // consume: the shifts run with every lane enabled (a DPP source lane that is masked off delivers nothing): take them
+        // first, unconditionally, then select
+#define GS_CONSUME(S)                                                                                                              \
+    {                                                                                                                              \
+        const float n001 = dpp_shl1_f(S##v000), n011 = dpp_shl1_f(S##v010), n101 = dpp_shl1_f(S##v100), n111 = dpp_shl1_f(S##v110);   \
+        const float v001 = S##fb ? S##f001 : n001, v011 = S##fb ? S##f011 : n011, v101 = S##fb ? S##f101 : n101, v111 = S##fb ? S##f111 : n111; \
+        const f32x2 p00 = {S##v000, v001}, p01 = {S##v010, v011}, p10 = {S##v100, v101}, p11 = {S##v110, v111};                    \
+        const f32x2 dy0 = p01 - p00, dy1 = p11 - p10;             /* d/dy on the x = 0 / x = 1 faces, at z and z + 1 */            \
+        const f32x2 c0 = p00 + S##wy * dy0, c1 = p10 + S##wy * dy1; /* y-lerped */                                                 \
+        const f32x2 dx = c1 - c0;                                 /* d/dx at z, z + 1 */                                           \
+        const f32x2 e = c0 + S##wx * dx;                          /* x,y-lerped value at z, z + 1 */                               \
+        const f32x2 dyx = dy0 + S##wx * (dy1 - dy0);              /* d/dy at z, z + 1 */                                           \
+        const float keep = S##act ? 1.f : 0.f;                                                                                     \
+        const float gz = keep * (e.y - e.x);                                                                                       \
+        const float gx = keep * fmaf(S##wz, dx.y - dx.x, dx.x), gy = keep * fmaf(S##wz, dyx.y - dyx.x, dyx.x);                     \
+        av = fmaf(keep, fmaf(S##wz, e.y - e.x, e.x), av);                                                                          \
+        const float sf = fmaf(S##t, sfs, sfb);                    /* (jb + jj) * step / |r0|, one rounding */                      \
+        const f32x2 gxy = {gx, gy}, one_sf = {1.f, sf};                                                                            \
+        a0xy += gxy;                                                                                                               \
+        a1xy += sf * gxy;                                                                                                          \
+        az += one_sf * gz;                                                                                                         \
+    }
+        for (int jj = LO; jj < HI; jj += 2) {                                      // wave-uniform trip count; two samples in flight
+            GS_DECL(a_);
+            GS_DECL(b_);
+            GS_ISSUE(a_, jj)
+            GS_ISSUE(b_, jj + 1)                                                   // past the end: clamped address, act = false
+            GS_CONSUME(a_)
+            GS_CONSUME(b_)
+        }
+#undef GS_DECL
+#undef GS_ISSUE
+#undef GS_CONSUME
+        val += (double)av;
+        s0[0] += (double)a0xy.x; s0[1] += (double)a0xy.y; s0[2] += (double)az.x;
+        s1[0] += (double)a1xy.x; s1[1] += (double)a1xy.y; s1[2] += (double)az.y;
+    }
+    const double s[3] = {gc.s00[0] + ixc * gc.sdx, gc.s00[1], gc.s00[2] + iz * gc.sdz};
+    double qv[3], gk[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) qv[a] = gc.ry[a][0] * s[0] + gc.ry[a][1] * s[1] + gc.ry[a][2] * s[2] + gc.t[a];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gk[k] = gc.rzx[0][k] * s0[0] + gc.rzx[1][k] * s0[1] + gc.rzx[2][k] * s0[2];
+    gk[3] = gk[4] = gk[5] = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double d3 = gc.a3[a][0] * qv[0] + gc.a3[a][1] * qv[1] + gc.a3[a][2] * qv[2];
+        const double d4 = gc.a4[a][0] * qv[0] + gc.a4[a][1] * qv[1] + gc.a4[a][2] * qv[2];
+        const double d5 = gc.a5[a][0] * s[0] + gc.a5[a][1] * s[1] + gc.a5[a][2] * s[2];
+        gk[3] += d3 * s0[a] + gc.app[0][a] * s1[a];
+        gk[4] += d4 * s0[a] + gc.app[1][a] * s1[a];
+        gk[5] += d5 * s0[a] + gc.app[2][a] * s1[a];
+    }
+    const size_t n_det = (size_t)g.ndx * g.ndz;
+    const size_t ray = (size_t)ixc * g.ndz + iz;
+    if (!FUSED) {
+        if (valid) {
+            proj[ray] = (float)val;
+            if (row_order == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) grad[k * n_det + ray] = (float)gk[k];
+            } else {
+                grad[0 * n_det + ray] = (float)gk[0]; grad[1 * n_det + ray] = (float)gk[1]; grad[2 * n_det + ray] = (float)gk[2];
+                grad[3 * n_det + ray] = (float)gk[4]; grad[4 * n_det + ray] = (float)gk[5]; grad[5 * n_det + ray] = (float)gk[3];
+            }
+        }
+    } else {
+        double part[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (valid) {
+            const float pv = (float)val;
+            const double res = (double)(bvec[(size_t)gc.b_row * n_det + ray] - pv);
+            if (resid) resid[(size_t)gc.slot * n_det + ray] = (float)res;
+            part[0] = 0.5 * res * res;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) part[1 + k] = -(double)(float)gk[k] * res;
+        }
+        __shared__ double sh[4][7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const double w = wave_sum_d(part[k]);
+            if (lane == 0) sh[wv][k] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x < 7) {
+            const int k = threadIdx.x;
+            atomicAdd(&red[(size_t)gc.slot * 7 + k], sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k]);
         }
     }
 }
@@ -1010,7 +1205,15 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static int upload_projc(tomo_ctx *ctx, const double *h_poses, int n, bool with_grad, ProjC **d_pc, GradC **d_gc)
+// how far the detector-z direction leaves the volume's z rows: |w_x| + |w_y| voxels per detector row.  The gradient kernels'
+// lanes run along detector z, so 64 x this is the drift of a wave across volume rows; beyond ~1 voxel the eight-gather kernel
+// (v2) slows down linearly and the four-gather + lane-shift kernel (v3) wins (measured crossover: |alpha| + |beta| ~ 0.9 deg)
+static inline bool grad_pose_is_tilted(const ProjC &c) { return fabs(c.w[0]) + fabs(c.w[1]) > 0.0157; }
+
+// Stage the per-projection constants.  With `n_first` the poses are ordered [those for which !grad_pose_is_tilted ..., tilted
+// ...] (stable), *n_first = size of the first group; GradC::slot keeps the caller's index.
+static int upload_projc(tomo_ctx *ctx, const double *h_poses, int n, bool with_grad, ProjC **d_pc, GradC **d_gc,
+                        const int32_t *h_rows = nullptr, int *n_first = nullptr)
 {
     const size_t pc_bytes = sizeof(ProjC) * (size_t)n;
     const size_t gc_off = (pc_bytes + 255) & ~(size_t)255;
@@ -1021,7 +1224,27 @@ static int upload_projc(tomo_ctx *ctx, const double *h_poses, int n, bool with_g
     if (rc) return rc;
     ProjC *hp = (ProjC *)ctx->h_stage;
     GradC *hg = (GradC *)((char *)ctx->h_stage + gc_off);
-    for (int i = 0; i < n; ++i) tomo_make_projc(ctx->g, h_poses + (size_t)i * TOMO_POSE_STRIDE, hp[i], with_grad ? &hg[i] : nullptr);
+    int lo = 0, hi = n;                                  // next free entry of the first group / one past the last free of the second
+    for (int pass = 0; pass < (n_first ? 2 : 1); ++pass) {
+        for (int i = (pass == 0 ? 0 : n - 1); pass == 0 ? i < n : i >= 0; i += (pass == 0 ? 1 : -1)) {
+            ProjC pc;
+            GradC gc;
+            tomo_make_projc(ctx->g, h_poses + (size_t)i * TOMO_POSE_STRIDE, pc, with_grad ? &gc : nullptr);
+            int at = i;
+            if (n_first) {
+                const bool tilted = grad_pose_is_tilted(pc);
+                if (pass == 0) { if (tilted) continue; at = lo++; }        // first group in ascending order
+                else { if (!tilted) continue; at = --hi; }                 // second group filled from the back, walking backwards
+            }
+            hp[at] = pc;
+            if (with_grad) {
+                gc.b_row = h_rows ? h_rows[i] : i;
+                gc.slot = i;
+                hg[at] = gc;
+            }
+        }
+    }
+    if (n_first) *n_first = lo;
     TOMO_HIP(ctx, hipMemcpyAsync(ctx->d_stage, ctx->h_stage, total, hipMemcpyHostToDevice, ctx->stream));
     *d_pc = (ProjC *)ctx->d_stage;
     if (d_gc) *d_gc = (GradC *)((char *)ctx->d_stage + gc_off);
@@ -1294,13 +1517,18 @@ extern "C" int tomo_proj_grad(tomo_ctx *ctx, const double *h_pose, const float *
     if (rc) return rc;
     ProjC *d_pc = nullptr;
     GradC *d_gc = nullptr;
-    rc = upload_projc(ctx, h_pose, 1, true, &d_pc, &d_gc);
+    int n_plain = 0;
+    rc = upload_projc(ctx, h_pose, 1, true, &d_pc, &d_gc, nullptr, &n_plain);
     if (rc) return rc;
-    if (ctx->grad_variant == 1)
+    const int variant = ctx->grad_variant == 4 ? (n_plain ? 2 : 3) : ctx->grad_variant;       // 4 = by tilt
+    if (variant == 1)
         TOMO_LAUNCH(ctx, "k_proj_grad", k_proj_grad<false>, ray_grid(g, 1), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, d_proj, d_grad,
                     (const float *)nullptr, (float *)nullptr, (double *)nullptr, g, row_order);
-    else
+    else if (variant == 2)
         TOMO_LAUNCH(ctx, "k_proj_grad", k_proj_grad_v2<false>, ray_grid(g, 1), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, d_proj, d_grad,
+                    (const float *)nullptr, (float *)nullptr, (double *)nullptr, g, row_order);
+    else
+        TOMO_LAUNCH(ctx, "k_proj_grad", k_proj_grad_v3<false>, ray_grid(g, 1), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, d_proj, d_grad,
                     (const float *)nullptr, (float *)nullptr, (double *)nullptr, g, row_order);
     return TOMO_OK;
 }
@@ -1308,8 +1536,17 @@ extern "C" int tomo_proj_grad(tomo_ctx *ctx, const double *h_pose, const float *
 extern "C" int tomo_cost_grad(tomo_ctx *ctx, const double *h_poses, int n, const float *d_vol, const float *d_b, double *h_cost,
                               double *h_grad6, float *d_resid)
 {
+    return tomo_cost_grad_rows(ctx, h_poses, n, d_vol, d_b, nullptr, n, h_cost, h_grad6, d_resid);
+}
+
+extern "C" int tomo_cost_grad_rows(tomo_ctx *ctx, const double *h_poses, int n, const float *d_vol, const float *d_b,
+                                   const int32_t *h_rows, int n_rows_total, double *h_cost, double *h_grad6, float *d_resid)
+{
     TOMO_NEED_GEOM(ctx);
     if (!h_poses || !d_vol || !d_b || !h_cost || !h_grad6 || n < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_cost_grad: bad args");
+    if (h_rows)
+        for (int i = 0; i < n; ++i)
+            if (h_rows[i] < 0 || h_rows[i] >= n_rows_total) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_cost_grad_rows: row index outside the table");
     if (n == 0) return TOMO_OK;
     if (n > TOMO_MAX_GRID_Z) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "tomo_cost_grad: more than 65535 projections per call");
     const TomoGeomC &g = ctx->g;
@@ -1319,15 +1556,27 @@ extern "C" int tomo_cost_grad(tomo_ctx *ctx, const double *h_poses, int n, const
     if (rc) return rc;
     ProjC *d_pc = nullptr;
     GradC *d_gc = nullptr;
-    rc = upload_projc(ctx, h_poses, n, true, &d_pc, &d_gc);
+    int n_plain = 0;                                      // staged order: [near-untilted poses ..., tilted poses ...]
+    rc = upload_projc(ctx, h_poses, n, true, &d_pc, &d_gc, h_rows, &n_plain);
     if (rc) return rc;
     TOMO_HIP(ctx, hipMemsetAsync(ctx->d_red, 0, sizeof(double) * (size_t)n * 7, ctx->stream));
-    if (ctx->grad_variant == 1)
-        TOMO_LAUNCH(ctx, "k_cost_grad", k_proj_grad<true>, ray_grid(g, n), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, (float *)nullptr,
-                    (float *)nullptr, d_b, d_resid, ctx->d_red, g, 0);
-    else
-        TOMO_LAUNCH(ctx, "k_cost_grad", k_proj_grad_v2<true>, grad_grid(g, n), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, (float *)nullptr,
-                    (float *)nullptr, d_b, d_resid, ctx->d_red, g, grad_zslow(g, n) ? 16 : 0);
+    // up to two launches: the first group with one kernel variant, the second with another (grad_variant 4: v2 / v3 by tilt)
+    const int var_a = ctx->grad_variant == 4 ? 2 : ctx->grad_variant, var_b = ctx->grad_variant == 4 ? 3 : ctx->grad_variant;
+    for (int part = 0; part < 2; ++part) {
+        const int first = part == 0 ? 0 : n_plain, cnt = part == 0 ? n_plain : n - n_plain, variant = part == 0 ? var_a : var_b;
+        if (cnt == 0) continue;
+        const ProjC *pc = d_pc + first;
+        const GradC *gc = d_gc + first;
+        if (variant == 1)
+            TOMO_LAUNCH(ctx, "k_cost_grad", k_proj_grad<true>, ray_grid(g, cnt), dim3(256), 0, pc, gc, ctx->d_volpad, (float *)nullptr,
+                        (float *)nullptr, d_b, d_resid, ctx->d_red, g, 0);
+        else if (variant == 2)
+            TOMO_LAUNCH(ctx, "k_cost_grad", k_proj_grad_v2<true>, grad_grid(g, cnt), dim3(256), 0, pc, gc, ctx->d_volpad, (float *)nullptr,
+                        (float *)nullptr, d_b, d_resid, ctx->d_red, g, grad_zslow(g, cnt) ? 16 : 0);
+        else
+            TOMO_LAUNCH(ctx, "k_cost_grad", k_proj_grad_v3<true>, grad_grid(g, cnt), dim3(256), 0, pc, gc, ctx->d_volpad, (float *)nullptr,
+                        (float *)nullptr, d_b, d_resid, ctx->d_red, g, grad_zslow(g, cnt) ? 16 : 0);
+    }
     TOMO_HIP(ctx, hipMemcpyAsync(ctx->h_red, ctx->d_red, sizeof(double) * (size_t)n * 7, hipMemcpyDeviceToHost, ctx->stream));
     TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < n; ++i) {

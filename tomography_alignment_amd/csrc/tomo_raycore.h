@@ -48,6 +48,8 @@ struct GradC {        // extras for the 6-DoF pose Jacobian of one projection (:
     double ry[3][3], t[3];
     double s00[3], sdx, sdz;            // untransformed (cor-shifted) source of ray (0,0) and pitches
     double app[3][3];                   // der rows 6-8: the three operators applied to (d - s)
+    int32_t b_row;                      // fused cost/gradient: row of the measured-projection table this pose is compared with
+    int32_t slot;                       // ... and the caller's index of this pose (where its 7 sums / residual row go)
 };
 
 struct TomoM3 { double m[3][3]; };

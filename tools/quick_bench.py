@@ -16,7 +16,7 @@ from tomography_alignment_amd.utilities.geometry import Geometry  # noqa: E402
 def poses(n_proj, tilt, rng):
     phi = np.linspace(0, np.pi, n_proj)
     if tilt:
-        a = np.deg2rad(rng.uniform(-1, 1, n_proj)); b = np.deg2rad(rng.uniform(-1, 1, n_proj))
+        a = np.deg2rad(rng.uniform(-tilt, tilt, n_proj)); b = np.deg2rad(rng.uniform(-tilt, tilt, n_proj))     # tilt = half-range in degrees
         xyz = np.zeros((n_proj, 3)); xyz[:, 0] = rng.uniform(-2, 2, n_proj); xyz[:, 2] = rng.uniform(-2, 2, n_proj)
     else:
         a = np.zeros(n_proj); b = np.zeros(n_proj); xyz = np.zeros((n_proj, 3))
@@ -43,7 +43,7 @@ def run(N, n_proj, what, tilt=True, reps=2, opts=None):
         be.ctx.timer_start(); fn(); ms = be.ctx.timer_stop(); best = min(best, ms)
     alg = {"fwd": 4 * N ** 3 + 4 * N * N, "adj": 8 * N ** 3 + 4 * N * N, "bpv": 8 * N ** 3 + 4 * N * N,
            "cg": 4 * N ** 3 + 4 * N * N + 28, "pg": 4 * N ** 3 + 28 * N * N}[what] * n_proj
-    print("%-4s N=%4d n_proj=%4d tilt=%d opts=%s : %9.2f ms  alg %.1f GB/s  (%.1f%% of 8 TB/s)  [%.3f ms/angle]"
+    print("%-4s N=%4d n_proj=%4d tilt=%g opts=%s : %9.2f ms  alg %.1f GB/s  (%.1f%% of 8 TB/s)  [%.3f ms/angle]"
           % (what, N, n_proj, tilt, opts, best, alg / best / 1e6, alg / best / 1e6 / 80.0, best / n_proj), flush=True)
     del vol, prj
     be.ctx.close()
@@ -60,5 +60,8 @@ if __name__ == "__main__":
             if k == "tilt":
                 continue
             opts[k] = int(v)
-        tilt = not any(p == "tilt=0" for p in parts[3:])
+        tilt = 1.0
+        for kv in parts[3:]:
+            if kv.startswith("tilt="):
+                tilt = float(kv[5:])
         run(N, n_proj, what, tilt=tilt, opts=opts)
