@@ -122,7 +122,7 @@ def main():
 
     # ---- per-kernel timing of the timed region (HIP events on the ctx stream)
     kern = {}
-    for name in ("k_fwd_v1", "k_fwd_v2", "k_fwd_tile", "k_fwd_tile_flat", "k_adj_v1", "k_adj_tile", "k_adj_tile_flat", "k_pad", "k_unpad", "k_absmax", "k_residual_scale", "k_update",
+    for name in ("k_fwd_v1", "k_fwd_v2", "k_fwd_tile", "k_fwd_tile_flat", "k_adj_v1", "k_adj_tile", "k_adj_tile_flat", "k_adj_gather_flat", "k_pad", "k_unpad", "k_absmax", "k_residual_scale", "k_update",
                  "k_vec", "allreduce_f32"):
         n, ms = ctx.profile_get(name)
         if n:
@@ -134,7 +134,7 @@ def main():
     alg_fwd = n_loc * (4.0 * N ** 3 + 4.0 * n_det)               # bytes per forward launch   
     alg_adj = n_loc * (8.0 * N ** 3 + 4.0 * n_det)               # bytes per back-projection launch
     fwd_name = next((k for k in ("k_fwd_tile_flat", "k_fwd_tile", "k_fwd_v2", "k_fwd_v1") if k in kern), None)
-    adj_name = next((k for k in ("k_adj_tile_flat", "k_adj_tile", "k_adj_v1") if k in kern), None)
+    adj_name = next((k for k in ("k_adj_gather_flat", "k_adj_tile_flat", "k_adj_tile", "k_adj_v1") if k in kern), None)
     cands = []
     if fwd_name:
         cands.append((kern[fwd_name]["ms_per_step"], fwd_name, alg_fwd))

@@ -94,6 +94,8 @@ TOMO_API int tomo_sync(tomo_ctx *ctx);
  *                    shift) -- nearly insensitive to tilt, fastest beyond |alpha| + |beta| ~ 1 deg;
  *                  4 (default) each pose of a call takes 2 or 3 by its tilt (two launches)
  *   "tile_flat"   1 (default): untilted projections (alpha = beta = 0, detector-z pitch 1) take the flat tile kernels
+ *   "adj_flat_gather" 1 (default): untilted projections on a unit lattice (detector pitch = step = voxel) take the gather-form
+ *                 adjoint (accumulators in registers, no atomics) instead of the LDS-atomic flat tile kernel
  *   "reuse_staged_volume" 1: the caller vouches that the volume passed to tomo_proj_grad / tomo_cost_grad / the ray-driven
  *                 forward has not changed since the previous such call with the same pointer, so its zero-padded staging
  *                 copy is reused (alignment loops evaluate hundreds of poses against one volume); default 0 */

@@ -320,18 +320,21 @@ def test_untilted_poses_take_the_flat_tile_kernels(PM, orc, shape, ndet):
     want = orc.forward(og, x, phi=phi, xyz_shift=xyz).ravel()
     wantT = orc.adjoint(og, y, phi=phi, xyz_shift=xyz)
     res = {}
-    for flat in (1, 0):
+    for flat, gather in ((1, 1), (1, 0), (0, 0)):     # gather-form adjoint / LDS-atomic flat adjoint / general tile kernels
         P = PM(geo)
         P.backend.ctx.set_option("tile_flat", flat)
+        P.backend.ctx.set_option("adj_flat_gather", gather)
         P.backend.ctx.profile_reset()
         P.backend.ctx.profile_enable(True)
         A = P.projection_matrix(phi=phi, xyz_shift=xyz)
-        res[flat] = (A.dot(x.ravel()), A.T.dot(y))
+        res[flat, gather] = (A.dot(x.ravel()), A.T.dot(y))
         P.backend.ctx.profile_enable(False)
-        used_flat = P.backend.ctx.profile_get("k_fwd_tile_flat")[0] + P.backend.ctx.profile_get("k_adj_tile_flat")[0]
-        assert (used_flat == 2) == bool(flat)
-        assert rel_max(res[flat][0], want) < TOL and rel_max(res[flat][1], wantT) < TOL
-    assert rel_max(res[1][0], res[0][0]) < 2e-6 and rel_max(res[1][1], res[0][1]) < 2e-6
+        n_launch = {k: P.backend.ctx.profile_get(k)[0] for k in ("k_fwd_tile_flat", "k_adj_tile_flat", "k_adj_gather_flat", "k_adj_tile")}
+        assert n_launch == {"k_fwd_tile_flat": flat, "k_adj_tile_flat": flat * (1 - gather), "k_adj_gather_flat": flat * gather,
+                            "k_adj_tile": 1 - flat}
+        assert rel_max(res[flat, gather][0], want) < TOL and rel_max(res[flat, gather][1], wantT) < TOL
+    assert rel_max(res[1, 0][0], res[0, 0][0]) < 2e-6 and rel_max(res[1, 0][1], res[0, 0][1]) < 2e-6
+    assert rel_max(res[1, 1][1], res[1, 0][1]) < 2e-6
 
 
 def test_mixed_tilted_and_untilted_call(PM, orc):
@@ -507,3 +510,7 @@ def test_properties_at_full_size_1024():
     assert np.sqrt(be.diff_sumsq(be.forward(flat, x, tmp), ax) / be.dot(ax, ax)) < 1e-6
     assert np.sqrt(be.diff_sumsq(be.adjoint(flat, y, tmp2), aty) / be.dot(aty, aty)) < 1e-5
     be.ctx.set_option("tile_flat", 1)
+    # ... and the gather-form flat adjoint (default, used above) against the LDS-atomic flat adjoint
+    be.ctx.set_option("adj_flat_gather", 0)
+    assert np.sqrt(be.diff_sumsq(be.adjoint(flat, y, tmp2), aty) / be.dot(aty, aty)) < 1e-6
+    be.ctx.set_option("adj_flat_gather", 1)

@@ -44,6 +44,7 @@ struct tomo_ctx {
     int adj_variant = 2;      // 1 global float atomics, 2 LDS tile fixed-point (default)
     int grad_variant = 4;     // 1 plain, 2 eight dword gathers + packed lerps, 3 four gathers + DPP neighbour shift, 4 (default) 2 or 3 per pose by tilt
     int tile_flat = 1;      // 1: untilted projections take the flat tile kernels
+    int adj_flat_gather = 1;  // 1: untilted unit lattices take the gather-form adjoint (k_adj_gather_flat) instead of the LDS-atomic flat kernel
     // timing / profiling
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profile_on = false;

@@ -679,6 +679,123 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// GATHER-form adjoint for untilted unit lattices (the poses of a plain parallel-beam scan: alpha = beta = 0, detector pitch =
+// step = voxel; any phi, translation, COR shift).  For such a lattice the adjoint separates:
+//     (A^T y)(X, Y, Z) = sum_ix  W(X, Y, ix) * Yz(ix, Z)
+//     Yz(ix, Z)   = (1 - tau) y[ix, Z - zc] + tau y[ix, Z - zc - 1]                 (every sample has z = iz + zc + tau)
+//     W(X, Y, ix) = sum_{j in [0, n)} tent(px(ix, j) - X) * tent(py(ix, j) - Y)       (tent(r) = 1 - |r| on [-1, 1))
+// and W does not depend on Z.  A wave owns 8 x 8 voxel columns x 64 planes with the 64 accumulators of a lane (= plane) in
+// registers for ALL projections -- no atomics, no fixed-point image, no flush, each voxel written once:
+//   1. lane = COLUMN: the <= 3 detector rows ix and <= 3 samples j per row that can reach the column are enumerated from the
+//      column's lattice coordinates; their positions are exact 32.32 fixed point (the forward kernels' lattice), the tents
+//      are evaluated from them, summed over j -> W0..W2 and the first row i0, per lane;
+//   2. lane = PLANE: the z-lerped sinogram rows the tile can touch (<= 16) are loaded once (coalesced) into a per-lane LDS
+//      column (every lane reads back only what it wrote: LDS as an indexable register file, no synchronisation);
+//   3. for each of the 64 columns (unrolled, accumulators statically indexed): i0 and W0..W2 are broadcast with v_readlane
+//      and the lane does 3 ds_read_b32 + 3 FMA.
+// Same sums as k_tile_flat<false> (which needs 4 ds_add_u32 per sample and lane), regrouped by voxel instead of by sample.
+// ------------------------------------------------------------------------------------------------
+#define GTX 8
+#define GTY 8
+#define GROWS 16
+#define GWAVES 4
+
+struct GfC {
+    int64_t fp0x, fp0y, fux, fuy, fdx, fdy;   // x, y of the 32.32 lattice  p = fp0 + ix fu + j fd
+    float m00, m01, m10, m11;                 // (ix, j) = M ((x, y) - p0)
+    float p0x, p0y, tau;
+    int32_t n, zc, slot;
+};
+
+__global__ __launch_bounds__(GWAVES * 64) void k_adj_gather_flat(const GfC *__restrict__ cs, int n_proj, const float *__restrict__ proj,
+                                                                 float *__restrict__ vol, TomoGeomC g, int xs, int xe)
+{
+    __shared__ float rows[GWAVES][GROWS][64];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0 = xs + (int)blockIdx.z * (2 * GTX) + (wv >> 1) * GTX, y0 = (int)blockIdx.y * (2 * GTY) + (wv & 1) * GTY, z0 = (int)blockIdx.x * 64;
+    if (x0 >= xe || y0 >= g.ny) return;                                 // wave-uniform; the kernel has no barriers
+    const int X = x0 + (lane >> 3), Y = y0 + (lane & 7), Z = z0 + lane;  // this lane's column (step 1) and plane (steps 2, 3)
+    float *myrows = &rows[wv][0][lane];
+    const size_t n_det = (size_t)g.ndx * g.ndz;
+    const float two_m32 = 2.3283064365386963e-10f;
+    float acc[GTX * GTY];
+#pragma unroll
+    for (int cc = 0; cc < GTX * GTY; ++cc) acc[cc] = 0.f;
+    for (int ip = 0; ip < n_proj; ++ip) {
+        const GfC &c = cs[ip];
+        // ---- 1a. candidates of this lane's column: rows i0..i0+2, samples j0..j0+2 (the footprint |dx|,|dy| < 1 maps to
+        //          |d ix| <= |m00|+|m01| < 1.5, likewise for j: three consecutive integers cover an interval shorter than 3)
+        const float qx = (float)X - c.p0x, qy = (float)Y - c.p0y;
+        const float a = c.m00 * qx + c.m01 * qy, b = c.m10 * qx + c.m11 * qy;
+        const int i0 = (int)ceilf(a - (fabsf(c.m00) + fabsf(c.m01) + 5e-3f));
+        const int j0 = (int)ceilf(b - (fabsf(c.m10) + fabsf(c.m11) + 5e-3f));
+        const int ix_lo = __builtin_amdgcn_readfirstlane(wave_min_i32(i0));
+        const int nrows = min(GROWS, __builtin_amdgcn_readfirstlane(wave_max_i32(i0)) + 3 - ix_lo);
+        // ---- 2. the z-lerped sinogram rows ix_lo .. ix_lo + nrows - 1 at this lane's plane
+        {
+            const int iz0 = Z - c.zc, iz1 = iz0 - 1;
+            const bool ok0 = iz0 >= 0 && iz0 < g.ndz, ok1 = iz1 >= 0 && iz1 < g.ndz;
+            const float *srow = proj + (size_t)c.slot * n_det;
+#pragma unroll
+            for (int r = 0; r < GROWS; ++r) {
+                const int ix = ix_lo + r;
+                if (r < nrows) {                                        // wave-uniform
+                    float y0v = 0.f, y1v = 0.f;
+                    if (ix >= 0 && ix < g.ndx) {
+                        const float *p = srow + (size_t)ix * g.ndz;
+                        if (ok0) y0v = p[iz0];
+                        if (ok1) y1v = p[iz1];
+                    }
+                    myrows[r * 64] = fmaf(c.tau, y1v - y0v, y0v);
+                }
+            }
+        }
+        // ---- 1b. W0..W2 from exact positions relative to the voxel centre
+        float W0, W1, W2;
+        {
+            int64_t rx = c.fp0x + (int64_t)i0 * c.fux + (int64_t)j0 * c.fdx - ((int64_t)X << 32);
+            int64_t ry = c.fp0y + (int64_t)i0 * c.fuy + (int64_t)j0 * c.fdy - ((int64_t)Y << 32);
+            float W[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int64_t sx = rx, sy = ry;
+                float wsum = 0.f;
+#pragma unroll
+                for (int mth = 0; mth < 3; ++mth) {
+                    const int hx = (int)(sx >> 32), hy = (int)(sy >> 32);
+                    const float fx = (float)(unsigned)sx * two_m32, fy = (float)(unsigned)sy * two_m32;
+                    const float wx = hx == 0 ? 1.f - fx : (hx == -1 ? fx : 0.f);     // tent on [-1, 1)
+                    const float wy = hy == 0 ? 1.f - fy : (hy == -1 ? fy : 0.f);
+                    wsum += ((unsigned)(j0 + mth) < (unsigned)c.n) ? wx * wy : 0.f;
+                    sx += c.fdx; sy += c.fdy;
+                }
+                W[k] = ((unsigned)(i0 + k) < (unsigned)g.ndx) ? wsum : 0.f;
+                rx += c.fux; ry += c.fuy;
+            }
+            W0 = W[0]; W1 = W[1]; W2 = W[2];
+        }
+        if (!__any(W0 != 0.f || W1 != 0.f || W2 != 0.f)) continue;         // this projection's rays miss the tile
+        const int slot0 = min(max(i0 - ix_lo, 0), GROWS - 3);               // < nrows - 2 by construction; clamped for safety
+        // ---- 3. accumulate: column cc's table entries are broadcast, the lane adds for its plane
+#pragma unroll
+        for (int cc = 0; cc < GTX * GTY; ++cc) {
+            const float *q = myrows + __builtin_amdgcn_readlane(slot0, cc) * 64;
+            acc[cc] = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, W0), cc)), q[0], acc[cc]);
+            acc[cc] = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, W1), cc)), q[64], acc[cc]);
+            acc[cc] = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, W2), cc)), q[128], acc[cc]);
+        }
+    }
+    if (Z < g.nz) {
+#pragma unroll
+        for (int cc = 0; cc < GTX * GTY; ++cc) {
+            const int Xc = x0 + (cc >> 3), Yc = y0 + (cc & 7);
+            if (Xc < xe && Yc < g.ny) vol[((size_t)Xc * g.ny + Yc) * g.nz + Z] += acc[cc];    // the wave owns these voxels
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // voxel-driven bilinear back-projector (src/back_projection.f90:25-32): one voxel per work-item,
 // lanes along z, loop over projections with the accumulator in a register; the voxel centre is
 // transformed on the fly (the reference re-reads a (3,n_vox) voxel_centers array per projection).
@@ -1284,16 +1401,22 @@ static bool invert3(const double m[3][3], double inv[3][3], double *det_out)
 // Per-projection constants of the tile kernels, staged to the device as [flat projections..., general projections...].
 // all_ok = false (nothing staged) when some projection's detector-z axis does not map mostly onto volume z (tilt beyond
 // ~45 deg) or its lattice is singular / out of fixed-point range: those calls take the ray-driven / atomic kernels.
-static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, bool *all_ok, double *weight_bound, int *n_flat)
+// Stage the tile kernels' constants in the order [gather-eligible flat ..., other flat ..., general ...]; the first *n_gather
+// also get a GfC record (for k_adj_gather_flat) in a second array behind the AdjC array (*d_gfc).
+static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, bool *all_ok, double *weight_bound, int *n_flat,
+                             int *n_gather = nullptr, const GfC **d_gfc = nullptr)
 {
     const TomoGeomC &g = ctx->g;
     *all_ok = false;
     *weight_bound = 2.0;
     *n_flat = 0;
+    if (n_gather) *n_gather = 0;
     TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    int rc = tomo_ensure_stage(ctx, sizeof(AdjC) * (size_t)std::max(n_proj, 1));
+    const size_t gf_off = (sizeof(AdjC) * (size_t)std::max(n_proj, 1) + 255) & ~(size_t)255;
+    int rc = tomo_ensure_stage(ctx, gf_off + sizeof(GfC) * (size_t)std::max(n_proj, 1));
     if (rc) return rc;
-    std::vector<AdjC> flat, gen;
+    std::vector<AdjC> gath, flat, gen;
+    std::vector<GfC> gfc;
     for (int i = 0; i < n_proj; ++i) {
         ProjC pc;
         tomo_make_projc(g, h_poses + (size_t)i * TOMO_POSE_STRIDE, pc, nullptr);
@@ -1320,14 +1443,36 @@ static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, b
         *weight_bound = std::max(*weight_bound, 2.0 / fabs(det));
         const bool untilted = a.fw[0] == 0 && a.fw[1] == 0 && a.fw[2] == ((int64_t)1 << 32) && a.fu[2] == 0 && a.fd[2] == 0 &&
                               ctx->tile_flat != 0;
-        (untilted ? flat : gen).push_back(a);
+        // gather-form adjoint: additionally the x-y lattice must be (close to) a unit lattice, so that three consecutive rows
+        // and three consecutive samples cover a voxel's footprint (2 * (|m_r0| + |m_r1| + 5e-3) < 3) -- true for detector
+        // pitch = step = voxel at any phi (sum <= sqrt 2)
+        const double ea = fabs(a.minv[0][0]) + fabs(a.minv[0][1]), eb = fabs(a.minv[2][0]) + fabs(a.minv[2][1]);
+        const bool gatherable = untilted && n_gather && ctx->adj_flat_gather != 0 && ea < 1.49 && eb < 1.49 &&
+                                fabs(a.minv[0][2]) < 1e-9 && fabs(a.minv[2][2]) < 1e-9;
+        if (gatherable) {
+            GfC q;
+            q.fp0x = a.fp0[0]; q.fp0y = a.fp0[1]; q.fux = a.fu[0]; q.fuy = a.fu[1]; q.fdx = a.fd[0]; q.fdy = a.fd[1];
+            q.m00 = (float)a.minv[0][0]; q.m01 = (float)a.minv[0][1]; q.m10 = (float)a.minv[2][0]; q.m11 = (float)a.minv[2][1];
+            q.p0x = (float)a.p0[0]; q.p0y = (float)a.p0[1];
+            q.zc = (int32_t)(a.fp0[2] >> 32);                                       // floor of the constant z offset
+            q.tau = (float)((double)(uint32_t)(a.fp0[2] & 0xffffffffll) / 4294967296.0);
+            q.n = a.n; q.slot = a.slot;
+            gath.push_back(a);
+            gfc.push_back(q);
+        } else
+            (untilted ? flat : gen).push_back(a);
     }
     AdjC *h = (AdjC *)ctx->h_stage;
     size_t k = 0;
+    for (const AdjC &a : gath) h[k++] = a;
     for (const AdjC &a : flat) h[k++] = a;
     for (const AdjC &a : gen) h[k++] = a;
-    *n_flat = (int)flat.size();
-    if (n_proj) TOMO_HIP(ctx, hipMemcpyAsync(ctx->d_stage, h, sizeof(AdjC) * (size_t)n_proj, hipMemcpyHostToDevice, ctx->stream));
+    GfC *hg = (GfC *)((char *)ctx->h_stage + gf_off);
+    for (size_t i = 0; i < gfc.size(); ++i) hg[i] = gfc[i];
+    *n_flat = (int)(gath.size() + flat.size());
+    if (n_gather) *n_gather = (int)gath.size();
+    if (d_gfc) *d_gfc = (const GfC *)((char *)ctx->d_stage + gf_off);
+    if (n_proj) TOMO_HIP(ctx, hipMemcpyAsync(ctx->d_stage, h, gf_off + sizeof(GfC) * gfc.size(), hipMemcpyHostToDevice, ctx->stream));
     *all_ok = true;
     return TOMO_OK;
 }
@@ -1409,26 +1554,38 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
     double weight_bound = 2.0;
     int n_flat = 0;
     if (ctx->adj_variant == 1 || n_proj <= 0 || grid.y > 65535 || grid.z > 65535) return TOMO_OK;
-    int rc = stage_tile_consts(ctx, h_poses, n_proj, &ok, &weight_bound, &n_flat);
+    int n_gather = 0;
+    const GfC *d_gfc = nullptr;
+    int rc = stage_tile_consts(ctx, h_poses, n_proj, &ok, &weight_bound, &n_flat, &n_gather, &d_gfc);
     if (rc) return rc;
     if (!ok) return TOMO_OK;
+    const int n_xt = (int)grid.z;
     xt0 = std::max(xt0, 0);
-    xt1 = std::min(xt1, (int)grid.z);
+    xt1 = std::min(xt1, n_xt);
     *done = true;
     if (xt1 <= xt0) return TOMO_OK;
     grid.z = (unsigned)(xt1 - xt0);
+    const AdjC *d_c = (const AdjC *)ctx->d_stage;
+    if (n_gather > 0) {
+        // the voxel x range the tile columns [xt0, xt1) finalise (the tile grid starts at x = -1)
+        const int xs = std::max(0, ATX * xt0 - 1), xe = (xt1 == n_xt) ? g.nx : std::min(g.nx, ATX * xt1 - 1);
+        if (xe > xs) {
+            const dim3 ggrid((g.nz + 63) / 64, (g.ny + 2 * GTY - 1) / (2 * GTY), (xe - xs + 2 * GTX - 1) / (2 * GTX));
+            TOMO_LAUNCH(ctx, "k_adj_gather_flat", k_adj_gather_flat, ggrid, dim3(GWAVES * 64), 0, d_gfc, n_gather, d_proj, d_vol, g, xs, xe);
+        }
+    }
+    if (n_proj == n_gather) return TOMO_OK;
     rc = tomo_ensure_red(ctx, 8);
     if (rc) return rc;
     unsigned *d_absmax = (unsigned *)(ctx->d_red + 4);
     TOMO_HIP(ctx, hipMemsetAsync(d_absmax, 0, sizeof(unsigned), ctx->stream));
     const int64_t n_y = (int64_t)n_det * n_proj;
     TOMO_LAUNCH(ctx, "k_absmax", k_absmax, dim3((unsigned)std::min<int64_t>((n_y + 255) / 256, 2048)), dim3(256), 0, d_proj, n_y, d_absmax);
-    const AdjC *d_c = (const AdjC *)ctx->d_stage;
-    if (n_flat > 0) {
+    if (n_flat > n_gather) {
         dim3 fgrid = tile_grid(g, FTZ);
         fgrid.z = grid.z;
-        TOMO_LAUNCH(ctx, "k_adj_tile_flat", k_tile_flat<false>, fgrid, dim3(ADJ_WAVES * 64), 0, d_c, n_flat, (float *)d_proj, d_vol, g,
-                    (const unsigned *)d_absmax, (float)weight_bound, xt0);
+        TOMO_LAUNCH(ctx, "k_adj_tile_flat", k_tile_flat<false>, fgrid, dim3(ADJ_WAVES * 64), 0, d_c + n_gather, n_flat - n_gather, (float *)d_proj,
+                    d_vol, g, (const unsigned *)d_absmax, (float)weight_bound, xt0);
     }
     if (n_proj > n_flat)
         TOMO_LAUNCH(ctx, "k_adj_tile", k_tile<false>, grid, dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, (float *)d_proj, d_vol, g,
