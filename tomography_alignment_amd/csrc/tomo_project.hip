@@ -684,20 +684,24 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
 //     (A^T y)(X, Y, Z) = sum_ix  W(X, Y, ix) * Yz(ix, Z)
 //     Yz(ix, Z)   = (1 - tau) y[ix, Z - zc] + tau y[ix, Z - zc - 1]                 (every sample has z = iz + zc + tau)
 //     W(X, Y, ix) = sum_{j in [0, n)} tent(px(ix, j) - X) * tent(py(ix, j) - Y)       (tent(r) = 1 - |r| on [-1, 1))
-// and W does not depend on Z.  A wave owns 8 x 8 voxel columns x 64 planes with the 64 accumulators of a lane (= plane) in
-// registers for ALL projections -- no atomics, no fixed-point image, no flush, each voxel written once:
+// and W does not depend on Z.  A wave owns 8 x 8 voxel columns x 64 planes with the 64 accumulators of a lane (= column) in
+// registers for ALL projections -- no atomics, no fixed-point image, no flush, each voxel written once (a lane finally
+// stores its column's 64 consecutive floats):
 //   1. lane = COLUMN: the <= 3 detector rows ix and <= 3 samples j per row that can reach the column are enumerated from the
 //      column's lattice coordinates; their positions are exact 32.32 fixed point (the forward kernels' lattice), the tents
-//      are evaluated from them, summed over j -> W0..W2 and the first row i0, per lane;
-//   2. lane = PLANE: the z-lerped sinogram rows the tile can touch (<= 16) are loaded once (coalesced) into a per-lane LDS
-//      column (every lane reads back only what it wrote: LDS as an indexable register file, no synchronisation);
-//   3. for each of the 64 columns (unrolled, accumulators statically indexed): i0 and W0..W2 are broadcast with v_readlane
-//      and the lane does 3 ds_read_b32 + 3 FMA.
+//      are evaluated from them, summed over j -> W0..W2 and the first row i0, per lane.  This table is the same for every
+//      z chunk of the tile: the four waves of a work-group (four z chunks) each compute it for every fourth projection and
+//      share it through a triple-buffered LDS table, one barrier per four projections;
+//   2. lane = PLANE: the z-lerped sinogram rows the tile can touch (<= 14) are loaded once (coalesced) into wave-private LDS
+//      rows (pitch 65 dwords, so that lanes reading different rows of one plane hit different banks);
+//   3. lane = COLUMN again, 64 plane accumulators per lane (statically indexed registers): per plane 3 ds_read_b32 at
+//      row(lane) + immediate plane offset and 3 FMA with the lane's own W0..W2 -- no broadcasts, no address arithmetic.
 // Same sums as k_tile_flat<false> (which needs 4 ds_add_u32 per sample and lane), regrouped by voxel instead of by sample.
 // ------------------------------------------------------------------------------------------------
 #define GTX 8
 #define GTY 8
-#define GROWS 16
+#define GROWS 14          // rows a tile can touch: i0 spreads over <= 7 (|m00| + |m01|) <= 10.2 -> 11 values, + 3
+#define GPITCH 65          // LDS row pitch in dwords: rows r, r+1, ... of one plane fall in different banks
 #define GWAVES 4
 
 struct GfC {
@@ -710,87 +714,139 @@ struct GfC {
 __global__ __launch_bounds__(GWAVES * 64) void k_adj_gather_flat(const GfC *__restrict__ cs, int n_proj, const float *__restrict__ proj,
                                                                  float *__restrict__ vol, TomoGeomC g, int xs, int xe)
 {
-    __shared__ float rows[GWAVES][GROWS][64];
+    __shared__ float rows[GWAVES][GROWS * GPITCH];
+    __shared__ float4 wtab[3][GWAVES][64];          // [group mod 3][projection of the group][column] = (i0, W0, W1, W2)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x0 = xs + (int)blockIdx.z * (2 * GTX) + (wv >> 1) * GTX, y0 = (int)blockIdx.y * (2 * GTY) + (wv & 1) * GTY, z0 = (int)blockIdx.x * 64;
-    if (x0 >= xe || y0 >= g.ny) return;                                 // wave-uniform; the kernel has no barriers
-    const int X = x0 + (lane >> 3), Y = y0 + (lane & 7), Z = z0 + lane;  // this lane's column (step 1) and plane (steps 2, 3)
-    float *myrows = &rows[wv][0][lane];
+    // the work-group owns 8 x 8 voxel columns; its four waves take four consecutive 64-plane chunks of them
+    const int x0 = xs + (int)blockIdx.z * GTX, y0 = (int)blockIdx.y * GTY, z0 = ((int)blockIdx.x * GWAVES + wv) * 64;
+    if (x0 >= xe || y0 >= g.ny) return;                                 // uniform over the WORK-GROUP (barriers below)
+    const bool zlive = z0 < g.nz;                                       // a wave past the volume still computes its share of tables
+    // a lane is a voxel COLUMN (X, Y) with 64 plane accumulators, except while loading sinogram rows, where it is plane Zl
+    const int X = x0 + (lane >> 3), Y = y0 + (lane & 7), Zl = z0 + lane;
+    float *wrows = rows[wv];
     const size_t n_det = (size_t)g.ndx * g.ndz;
     const float two_m32 = 2.3283064365386963e-10f;
-    float acc[GTX * GTY];
+    float acc[64];
 #pragma unroll
-    for (int cc = 0; cc < GTX * GTY; ++cc) acc[cc] = 0.f;
-    for (int ip = 0; ip < n_proj; ++ip) {
-        const GfC &c = cs[ip];
-        // ---- 1a. candidates of this lane's column: rows i0..i0+2, samples j0..j0+2 (the footprint |dx|,|dy| < 1 maps to
-        //          |d ix| <= |m00|+|m01| < 1.5, likewise for j: three consecutive integers cover an interval shorter than 3)
-        const float qx = (float)X - c.p0x, qy = (float)Y - c.p0y;
-        const float a = c.m00 * qx + c.m01 * qy, b = c.m10 * qx + c.m11 * qy;
-        const int i0 = (int)ceilf(a - (fabsf(c.m00) + fabsf(c.m01) + 5e-3f));
-        const int j0 = (int)ceilf(b - (fabsf(c.m10) + fabsf(c.m11) + 5e-3f));
-        const int ix_lo = __builtin_amdgcn_readfirstlane(wave_min_i32(i0));
-        const int nrows = min(GROWS, __builtin_amdgcn_readfirstlane(wave_max_i32(i0)) + 3 - ix_lo);
-        // ---- 2. the z-lerped sinogram rows ix_lo .. ix_lo + nrows - 1 at this lane's plane
-        {
-            const int iz0 = Z - c.zc, iz1 = iz0 - 1;
-            const bool ok0 = iz0 >= 0 && iz0 < g.ndz, ok1 = iz1 >= 0 && iz1 < g.ndz;
-            const float *srow = proj + (size_t)c.slot * n_det;
+    for (int p = 0; p < 64; ++p) acc[p] = 0.f;
+
+    // ---- 1. the weight table of this lane's column for projection IPX -> wtab[GRP % 3][IPX % GWAVES][lane].  The table does not
+    //         depend on z: the four waves share it, wave w computes the projections 4 g + w (one barrier per four projections).
+    //   candidates: rows i0..i0+2, samples j0..j0+2 (the footprint |dx|,|dy| < 1 maps to |d ix| <= |m00|+|m01| < 1.5, likewise
+    //   for j: three consecutive integers cover an interval shorter than 3); W_k from exact 32.32 positions relative to the voxel
+#define G_TABLE(IPX)                                                                                                       \
+    {                                                                                                                      \
+        float4 t4 = {0.f, 0.f, 0.f, 0.f};                                                                                  \
+        if ((IPX) < n_proj) {                                                                                              \
+            const GfC &ct = cs[IPX];                                                                                       \
+            const float qx = (float)X - ct.p0x, qy = (float)Y - ct.p0y;                                                    \
+            const float a = ct.m00 * qx + ct.m01 * qy, b = ct.m10 * qx + ct.m11 * qy;                                      \
+            const int i0 = (int)ceilf(a - (fabsf(ct.m00) + fabsf(ct.m01) + 5e-3f));                                        \
+            const int j0 = (int)ceilf(b - (fabsf(ct.m10) + fabsf(ct.m11) + 5e-3f));                                        \
+            int64_t rx = ct.fp0x + (int64_t)i0 * ct.fux + (int64_t)j0 * ct.fdx - ((int64_t)X << 32);                       \
+            int64_t ry = ct.fp0y + (int64_t)i0 * ct.fuy + (int64_t)j0 * ct.fdy - ((int64_t)Y << 32);                       \
+            float W[3];                                                                                                    \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                                \
+                int64_t sx = rx, sy = ry;                                                                                  \
+                float wsum = 0.f;                                                                                          \
+                _Pragma("unroll") for (int mth = 0; mth < 3; ++mth) {                                                      \
+                    const int hx = (int)(sx >> 32), hy = (int)(sy >> 32);                                                  \
+                    const float fx = (float)(unsigned)sx * two_m32, fy = (float)(unsigned)sy * two_m32;                    \
+                    const float wx = hx == 0 ? 1.f - fx : (hx == -1 ? fx : 0.f); /* tent on [-1, 1) */                     \
+                    const float wy = hy == 0 ? 1.f - fy : (hy == -1 ? fy : 0.f);                                           \
+                    wsum += ((unsigned)(j0 + mth) < (unsigned)ct.n) ? wx * wy : 0.f;                                       \
+                    sx += ct.fdx; sy += ct.fdy;                                                                            \
+                }                                                                                                          \
+                W[k] = ((unsigned)(i0 + k) < (unsigned)g.ndx) ? wsum : 0.f;                                                \
+                rx += ct.fux; ry += ct.fuy;                                                                                \
+            }                                                                                                              \
+            t4.x = __builtin_bit_cast(float, i0); t4.y = W[0]; t4.z = W[1]; t4.w = W[2];                                   \
+        }                                                                                                                  \
+        wtab[((IPX) / GWAVES) % 3][(IPX) % GWAVES][lane] = t4;                                                             \
+    }
+    // ---- 2a. fetch projection IPX's table entry and ISSUE the 32 loads of the sinogram rows the tile can touch: rows
+    //          ix_lo .. ix_lo+13 at this lane's PLANE (coalesced), from clamped -- always valid -- addresses, masked when used.
+    //          Straight-line on purpose (with a branch per row every row waited for its own round trip to memory).  The
+    //          loads are consumed one projection later: they fly while the previous projection accumulates.
+    float4 tn;
+    int ix_lo_n, nrows_n;
+    float y0v[GROWS], y1v[GROWS];
+#define G_SETUP(IPX)                                                                                                       \
+    {                                                                                                                      \
+        tn = wtab[((IPX) / GWAVES) % 3][(IPX) % GWAVES][lane];                                                             \
+        const int i0s = __builtin_bit_cast(int, tn.x);                                                                     \
+        ix_lo_n = __builtin_amdgcn_readfirstlane(wave_min_i32(i0s));                                                       \
+        nrows_n = min(GROWS, __builtin_amdgcn_readfirstlane(wave_max_i32(i0s)) + 3 - ix_lo_n);                             \
+        if (zlive) {                                                                                                       \
+            const GfC &cn = cs[IPX];                                                                                       \
+            const int iz0 = Zl - cn.zc;                                                                                    \
+            const float *srow = proj + (size_t)cn.slot * n_det;                                                            \
+            const float *p0 = srow + min(max(iz0, 0), g.ndz - 1), *p1 = srow + min(max(iz0 - 1, 0), g.ndz - 1);            \
+            _Pragma("unroll") for (int r = 0; r < GROWS; ++r) {                                                            \
+                const size_t ro = (size_t)min(max(ix_lo_n + r, 0), g.ndx - 1) * g.ndz; /* wave-uniform */                  \
+                y0v[r] = p0[ro];                                                                                           \
+                y1v[r] = p1[ro];                                                                                           \
+            }                                                                                                              \
+        }                                                                                                                  \
+    }
+    const int n_grp = (n_proj + GWAVES - 1) / GWAVES;
+    if (n_grp > 0) {
+        G_TABLE(wv)                                                     // group 0
+        __syncthreads();
+        G_SETUP(0)
+    }
+    for (int grp = 0; grp < n_grp; ++grp) {
+        if (grp + 1 < n_grp) G_TABLE((grp + 1) * GWAVES + wv)           // next group's tables: a third buffer, nobody reads it yet
+        __syncthreads();                                                // ... and everybody is done with group grp - 1's buffer
+        for (int ip = grp * GWAVES; ip < min(n_proj, (grp + 1) * GWAVES); ++ip) {
+            const GfC &c = cs[ip];
+            const float4 t = tn;
+            const int i0 = __builtin_bit_cast(int, t.x), ix_lo = ix_lo_n, nrows = nrows_n;
+            const float W0 = t.y, W1 = t.z, W2 = t.w;
+            const bool hit = zlive && __any(W0 != 0.f || W1 != 0.f || W2 != 0.f);   // else this projection's rays miss the tile
+            // ---- 2b. z-lerp the rows loaded one projection ago into the wave's LDS rows (lane = plane)
+            if (hit) {
+                const int iz0 = Zl - c.zc, iz1 = iz0 - 1;
+                const bool ok0 = iz0 >= 0 && iz0 < g.ndz, ok1 = iz1 >= 0 && iz1 < g.ndz;
 #pragma unroll
-            for (int r = 0; r < GROWS; ++r) {
-                const int ix = ix_lo + r;
-                if (r < nrows) {                                        // wave-uniform
-                    float y0v = 0.f, y1v = 0.f;
-                    if (ix >= 0 && ix < g.ndx) {
-                        const float *p = srow + (size_t)ix * g.ndz;
-                        if (ok0) y0v = p[iz0];
-                        if (ok1) y1v = p[iz1];
-                    }
-                    myrows[r * 64] = fmaf(c.tau, y1v - y0v, y0v);
+                for (int r = 0; r < GROWS; ++r) {
+                    const bool rowok = r < nrows && (unsigned)(ix_lo + r) < (unsigned)g.ndx;   // wave-uniform
+                    const float a0 = (rowok && ok0) ? y0v[r] : 0.f, a1 = (rowok && ok1) ? y1v[r] : 0.f;
+                    wrows[r * GPITCH + lane] = fmaf(c.tau, a1 - a0, a0);
                 }
             }
-        }
-        // ---- 1b. W0..W2 from exact positions relative to the voxel centre
-        float W0, W1, W2;
-        {
-            int64_t rx = c.fp0x + (int64_t)i0 * c.fux + (int64_t)j0 * c.fdx - ((int64_t)X << 32);
-            int64_t ry = c.fp0y + (int64_t)i0 * c.fuy + (int64_t)j0 * c.fdy - ((int64_t)Y << 32);
-            float W[3];
+            if (ip + 1 < n_proj) G_SETUP(ip + 1)                        // the next group's table is already published
+            // ---- 3. accumulate, lane = column: its three rows start at slot0; plane p is an immediate offset.  The LDS rows were
+            //         written by this same wave (LDS operations of a wave execute in order), no other wave touches them.
+            if (hit) {
+                const int slot0 = min(max(i0 - ix_lo, 0), GROWS - 3);       // <= nrows - 3 by construction; clamped for safety
+                const float *q = wrows + slot0 * GPITCH;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                int64_t sx = rx, sy = ry;
-                float wsum = 0.f;
-#pragma unroll
-                for (int mth = 0; mth < 3; ++mth) {
-                    const int hx = (int)(sx >> 32), hy = (int)(sy >> 32);
-                    const float fx = (float)(unsigned)sx * two_m32, fy = (float)(unsigned)sy * two_m32;
-                    const float wx = hx == 0 ? 1.f - fx : (hx == -1 ? fx : 0.f);     // tent on [-1, 1)
-                    const float wy = hy == 0 ? 1.f - fy : (hy == -1 ? fy : 0.f);
-                    wsum += ((unsigned)(j0 + mth) < (unsigned)c.n) ? wx * wy : 0.f;
-                    sx += c.fdx; sy += c.fdy;
+                for (int p = 0; p < 64; ++p) {
+                    acc[p] = fmaf(W0, q[p], acc[p]);
+                    acc[p] = fmaf(W1, q[GPITCH + p], acc[p]);
+                    acc[p] = fmaf(W2, q[2 * GPITCH + p], acc[p]);
                 }
-                W[k] = ((unsigned)(i0 + k) < (unsigned)g.ndx) ? wsum : 0.f;
-                rx += c.fux; ry += c.fuy;
             }
-            W0 = W[0]; W1 = W[1]; W2 = W[2];
-        }
-        if (!__any(W0 != 0.f || W1 != 0.f || W2 != 0.f)) continue;         // this projection's rays miss the tile
-        const int slot0 = min(max(i0 - ix_lo, 0), GROWS - 3);               // < nrows - 2 by construction; clamped for safety
-        // ---- 3. accumulate: column cc's table entries are broadcast, the lane adds for its plane
-#pragma unroll
-        for (int cc = 0; cc < GTX * GTY; ++cc) {
-            const float *q = myrows + __builtin_amdgcn_readlane(slot0, cc) * 64;
-            acc[cc] = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, W0), cc)), q[0], acc[cc]);
-            acc[cc] = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, W1), cc)), q[64], acc[cc]);
-            acc[cc] = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, W2), cc)), q[128], acc[cc]);
         }
     }
-    if (Z < g.nz) {
+#undef G_TABLE
+#undef G_SETUP
+    // ---- store: the lane's column is 64 consecutive floats of the volume
+    if (zlive && X < xe && Y < g.ny) {
+        float *dst = vol + ((size_t)X * g.ny + Y) * g.nz + z0;
+        if (z0 + 64 <= g.nz && (g.nz & 3) == 0) {
 #pragma unroll
-        for (int cc = 0; cc < GTX * GTY; ++cc) {
-            const int Xc = x0 + (cc >> 3), Yc = y0 + (cc & 7);
-            if (Xc < xe && Yc < g.ny) vol[((size_t)Xc * g.ny + Yc) * g.nz + Z] += acc[cc];    // the wave owns these voxels
+            for (int p = 0; p < 64; p += 4) {
+                float4 v = *(float4 *)(dst + p);
+                v.x += acc[p]; v.y += acc[p + 1]; v.z += acc[p + 2]; v.w += acc[p + 3];
+                *(float4 *)(dst + p) = v;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 64; ++p)
+                if (z0 + p < g.nz) dst[p] += acc[p];
         }
     }
 }
@@ -1447,7 +1503,7 @@ static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, b
         // and three consecutive samples cover a voxel's footprint (2 * (|m_r0| + |m_r1| + 5e-3) < 3) -- true for detector
         // pitch = step = voxel at any phi (sum <= sqrt 2)
         const double ea = fabs(a.minv[0][0]) + fabs(a.minv[0][1]), eb = fabs(a.minv[2][0]) + fabs(a.minv[2][1]);
-        const bool gatherable = untilted && n_gather && ctx->adj_flat_gather != 0 && ea < 1.49 && eb < 1.49 &&
+        const bool gatherable = untilted && n_gather && ctx->adj_flat_gather != 0 && ea < 1.45 && eb < 1.49 &&      // ea: see GROWS
                                 fabs(a.minv[0][2]) < 1e-9 && fabs(a.minv[2][2]) < 1e-9;
         if (gatherable) {
             GfC q;
@@ -1570,7 +1626,7 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
         // the voxel x range the tile columns [xt0, xt1) finalise (the tile grid starts at x = -1)
         const int xs = std::max(0, ATX * xt0 - 1), xe = (xt1 == n_xt) ? g.nx : std::min(g.nx, ATX * xt1 - 1);
         if (xe > xs) {
-            const dim3 ggrid((g.nz + 63) / 64, (g.ny + 2 * GTY - 1) / (2 * GTY), (xe - xs + 2 * GTX - 1) / (2 * GTX));
+            const dim3 ggrid((g.nz + 64 * GWAVES - 1) / (64 * GWAVES), (g.ny + GTY - 1) / GTY, (xe - xs + GTX - 1) / GTX);
             TOMO_LAUNCH(ctx, "k_adj_gather_flat", k_adj_gather_flat, ggrid, dim3(GWAVES * 64), 0, d_gfc, n_gather, d_proj, d_vol, g, xs, xe);
         }
     }
