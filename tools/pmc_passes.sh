@@ -11,7 +11,7 @@ while read -r grp; do
   timeout -k 10 240 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/$out/p$i -o run -- python3 $R/tools/quick_bench.py $job > $R/gpurun_out/$out.p$i.log 2>&1 || { echo "pass $i failed: $grp"; tail -3 $R/gpurun_out/$out.p$i.log; exit 1; }
 done <<'GRP'
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD
-SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_WAVES SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS
+SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_WAVES SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS
 TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum
 TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum
 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum
