@@ -587,7 +587,15 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
             const float fux = (float)c.u[0], fuy = (float)c.u[1], fdx = (float)c.d[0], fdy = (float)c.d[1];
             const int iz = izoff + lane;
             const bool ray_ok = lane < FTZ && iz >= 0 && iz < g.ndz;   // the ray this lane owns (the last plane is halo only)
-            const int64_t ldx = (int64_t)lane * c.fd[0], ldy = (int64_t)lane * c.fd[1];   // sample `lane` of a chunk, relative to its first
+            int64_t ldx = (int64_t)lane * c.fd[0], ldy = (int64_t)lane * c.fd[1];   // sample `lane` of a chunk, relative to its first
+            // The row loop below runs ~24 times per (tile, projection).  Keep what it needs in registers: left to itself the
+            // compiler re-loaded the lattice constants from memory in every row (scalar loads + wait) and rebuilt lane * fd with
+            // 64 x 64-bit multiplies.  The empty asm statements make the values opaque, so they can be neither rematerialised
+            // nor folded back into a multiply.
+            int64_t k_fux = c.fu[0], k_fuy = c.fu[1], k_fdx = c.fd[0], k_fdy = c.fd[1];
+            asm volatile("" : "+v"(ldx), "+v"(ldy));
+            asm volatile("" : "+s"(k_fux), "+s"(k_fuy), "+s"(k_fdx), "+s"(k_fdy));
+            float *const proj_c = proj + (size_t)c.slot * n_det + iz;
 
             for (int r0 = 0; r0 < n_rows_w; r0 += 64) {
                 int v_jlo = 0, v_jhi = 0;
@@ -615,12 +623,12 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
                     }
                 }
                 const int r_end = min(64, n_rows_w - r0);
-                for (int r = 0; r < r_end; ++r) {
+                // row bases advance incrementally: tile-relative 32.32 position of sample 0 and the row's sinogram pointer
+                int64_t rbx = c.fp0[0] + (int64_t)(ix_lo + r0) * k_fux - orgx, rby = c.fp0[1] + (int64_t)(ix_lo + r0) * k_fuy - orgy;
+                float *pr = proj_c + (size_t)(ix_lo + r0) * g.ndz;
+                for (int r = 0; r < r_end; ++r, rbx += k_fux, rby += k_fuy, pr += g.ndz) {
                     const int jlo = __builtin_amdgcn_readlane(v_jlo, r), jhi = __builtin_amdgcn_readlane(v_jhi, r);
                     if (jhi <= jlo) continue;
-                    const int ix = ix_lo + r0 + r;
-                    float *pr = proj + (size_t)c.slot * n_det + (size_t)ix * g.ndz + iz;
-                    const int64_t rbx = c.fp0[0] + (int64_t)ix * c.fu[0] - orgx, rby = c.fp0[1] + (int64_t)ix * c.fu[1] - orgy;
                     float S = 0.f;            // forward: sum over samples of the x,y-interpolated plane `lane`
                     float yt = 0.f;           // adjoint: what this row adds to plane `lane` per unit x,y weight (fixed-point scaled)
                     if (!FWD) {
@@ -630,7 +638,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
                     }
                     for (int jc = jlo; jc < jhi; jc += (FWD ? FTAB : 64)) {
                         // one lane per SAMPLE: cell, ownership in x,y and the four x,y weights of sample jc + lane
-                        const int64_t px = rbx + (int64_t)jc * c.fd[0] + ldx, py = rby + (int64_t)jc * c.fd[1] + ldy;
+                        const int64_t px = (rbx + (int64_t)jc * k_fdx) + ldx, py = (rby + (int64_t)jc * k_fdy) + ldy;   // uniform part on the SALU
                         const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32);
                         const bool own = (lx | ly) < (unsigned)ATX && jc + lane < jhi && (!FWD || lane < FTAB);
                         const unsigned t_e = own ? (__umul24(lx, ALY * FLZ) + __umul24(ly, FLZ)) * 4u : 0xffffffffu;
