@@ -66,6 +66,22 @@ def test_tile_kernels_agree_with_ray_driven_kernels(seed):
             assert e < 5e-6, ("adjoint", k, shape, ndet, step, phi, alpha, beta, xyz)
         else:
             assert np.all(a_tile == 0)
+        if k % 3 == 1:
+            # the pieces the pipelined multi-GPU back-projection is made of: random x-slab splits add up to the whole, and
+            # accumulate=True adds to what is there (device buffers, through the backend)
+            from tomography_alignment_amd import _lib
+            be = P.backend
+            poses = _lib.poses_array(phi, alpha, beta, xyz, cor)
+            ctx.set_option("fwd_variant", 3)
+            ctx.set_option("adj_variant", 2)
+            d_y, d_v = be.upload(y), be.zeros(int(np.prod(shape)))
+            n_xt, _ = be.xslab_info()
+            cuts = sorted(set([0, n_xt] + [int(c) for c in rng.integers(0, n_xt + 1, 2)]))
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                be.adjoint_xslab(poses, d_y, d_v, a, b)
+            assert rel_max(d_v.download(), a_tile) < 2e-6 or np.max(np.abs(a_tile)) == 0, ("xslab", k, shape, cuts)
+            be.adjoint(poses, d_y, d_v, accumulate=True)
+            assert rel_max(d_v.download(), 2.0 * a_tile) < 2e-6 or np.max(np.abs(a_tile)) == 0, ("accumulate", k, shape)
         # adjointness of the tile pair on the same random data
         lhs = float(np.dot(f_tile.astype(np.float64), y.astype(np.float64)))
         rhs = float(np.dot(x.ravel().astype(np.float64), a_tile.astype(np.float64)))
