@@ -393,7 +393,8 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
             const float fu[3] = {(float)c.u[0], (float)c.u[1], (float)c.u[2]}, fw[3] = {(float)c.w[0], (float)c.w[1], (float)c.w[2]};
             const float fd[3] = {(float)c.d[0], (float)c.d[1], (float)c.d[2]};
             // per-lane part of the fixed-point position: lane * fw  (the row adds the uniform rest)
-            const int64_t lw0 = (int64_t)lane * c.fw[0], lw1 = (int64_t)lane * c.fw[1], lw2 = (int64_t)lane * c.fw[2];
+            int64_t lw0 = (int64_t)lane * c.fw[0], lw1 = (int64_t)lane * c.fw[1], lw2 = (int64_t)lane * c.fw[2];
+            asm volatile("" : "+v"(lw0), "+v"(lw1), "+v"(lw2));      // opaque: or the compiler rebuilds them with 64-bit multiplies per chunk
 
             for (int r0 = 0; r0 < n_rows_w; r0 += 64) {
                 // row set-up, one detector row per LANE (row r0+lane of this wave), broadcast below with v_readlane:
