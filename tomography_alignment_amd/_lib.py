@@ -12,6 +12,9 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# Multi-process GPU work on this platform needs dmabuf IPC (RCCL's peer buffers); the variable is read when the HIP runtime
+# initialises, i.e. at the first call into the library, so it is set -- if the launcher has not -- before the library loads.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 LIB_PATH = os.environ.get("TOMO_HIP_LIB") or os.path.join(_HERE, "libtomo_hip.so")   # override: development builds only
 POSE_STRIDE = 7
 COMM_ID_BYTES = 128
