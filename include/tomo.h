@@ -94,6 +94,8 @@ TOMO_API int tomo_sync(tomo_ctx *ctx);
  *                    shift) -- nearly insensitive to tilt, fastest beyond |alpha| + |beta| ~ 1 deg;
  *                  4 (default) each pose of a call takes 2 or 3 by its tilt (two launches)
  *   "tile_flat"   1 (default): untilted projections (alpha = beta = 0, detector-z pitch 1) take the flat tile kernels
+ *   "fwd_flat_ztiles" 2 (default): the flat forward kernel owns two z-adjacent tiles per work-group and builds each detector
+ *                 row's sample table once for both; 1: one tile per work-group
  *   "adj_flat_gather" 1 (default): untilted projections on a unit lattice (detector pitch = step = voxel) take the gather-form
  *                 adjoint (accumulators in registers, no atomics) instead of the LDS-atomic flat tile kernel
  *   "reuse_staged_volume" 1: the caller vouches that the volume passed to tomo_proj_grad / tomo_cost_grad / the ray-driven

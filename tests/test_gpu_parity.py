@@ -324,6 +324,7 @@ def test_untilted_poses_take_the_flat_tile_kernels(PM, orc, shape, ndet):
         P = PM(geo)
         P.backend.ctx.set_option("tile_flat", flat)
         P.backend.ctx.set_option("adj_flat_gather", gather)
+        P.backend.ctx.set_option("fwd_flat_ztiles", 2 if gather else 1)     # two-z-tile forward with the gather adjoint, else the one-tile kernel
         P.backend.ctx.profile_reset()
         P.backend.ctx.profile_enable(True)
         A = P.projection_matrix(phi=phi, xyz_shift=xyz)
@@ -334,7 +335,7 @@ def test_untilted_poses_take_the_flat_tile_kernels(PM, orc, shape, ndet):
                             "k_adj_tile": 1 - flat}
         assert rel_max(res[flat, gather][0], want) < TOL and rel_max(res[flat, gather][1], wantT) < TOL
     assert rel_max(res[1, 0][0], res[0, 0][0]) < 2e-6 and rel_max(res[1, 0][1], res[0, 0][1]) < 2e-6
-    assert rel_max(res[1, 1][1], res[1, 0][1]) < 2e-6
+    assert rel_max(res[1, 1][1], res[1, 0][1]) < 2e-6 and rel_max(res[1, 1][0], res[1, 0][0]) < 2e-6
 
 
 def test_mixed_tilted_and_untilted_call(PM, orc):
@@ -510,6 +511,9 @@ def test_properties_at_full_size_1024():
     assert np.sqrt(be.diff_sumsq(be.forward(flat, x, tmp), ax) / be.dot(ax, ax)) < 1e-6
     assert np.sqrt(be.diff_sumsq(be.adjoint(flat, y, tmp2), aty) / be.dot(aty, aty)) < 1e-5
     be.ctx.set_option("tile_flat", 1)
+    be.ctx.set_option("fwd_flat_ztiles", 1)                      # one-tile forward kernel against the two-tile one used above
+    assert np.sqrt(be.diff_sumsq(be.forward(flat, x, tmp), ax) / be.dot(ax, ax)) < 1e-6
+    be.ctx.set_option("fwd_flat_ztiles", 2)
     # ... and the gather-form flat adjoint (default, used above) against the LDS-atomic flat adjoint
     be.ctx.set_option("adj_flat_gather", 0)
     assert np.sqrt(be.diff_sumsq(be.adjoint(flat, y, tmp2), aty) / be.dot(aty, aty)) < 1e-6

@@ -736,6 +736,176 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// Forward flat kernel over NZT z-adjacent tiles per work-group.  60 % of k_tile_flat<true>'s time is per-row set-up (sample
+// table, row bases, compaction: ~115 issue slots per row against ~130 for the row's samples) and that set-up does not depend on
+// z: here a work-group of FZ_WAVES waves holds the LDS images of NZT tiles stacked in z, builds each row's table once and runs
+// the sample loop against every image.  NZT = 2 with 16 waves uses 148 KB of the 160 KB LDS for the two images, with the same
+// number of waves per CU as two 8-wave work-groups of the one-image kernel.
+// ------------------------------------------------------------------------------------------------
+#define FZ_WAVES 16
+template <int NZT>
+__global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
+                                                              const float *__restrict__ vol, TomoGeomC g)
+{
+    __shared__ float img[NZT][ALX * ALY * FLZ];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int z0 = -1 + (int)blockIdx.x * (NZT * FTZ), y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + (int)blockIdx.z * ATX;
+    bool live[NZT];
+    bool any_live = false;
+#pragma unroll
+    for (int k = 0; k < NZT; ++k) {
+        bool any_nz = false;
+        for (int e = threadIdx.x; e < ALX * ALY * FLZ; e += FZ_WAVES * 64) {
+            const int lz = e % FLZ, t2 = e / FLZ, ly = t2 % ALY, lx = t2 / ALY;
+            const int gx = x0 + lx, gy = y0 + ly, gz = z0 + k * FTZ + lz;
+            float v = 0.f;
+            if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz) v = vol[((size_t)gx * g.ny + gy) * g.nz + gz];
+            img[k][e] = v;
+            any_nz |= (v != 0.f);
+        }
+        live[k] = __syncthreads_or(any_nz) != 0;                      // an all-zero tile contributes nothing to any ray
+        any_live |= live[k];
+    }
+    if (!any_live) return;
+    const float bcx = (float)x0 + 0.5f * ATX, bcy = (float)y0 + 0.5f * ATY;
+    const int64_t orgx = (int64_t)x0 << 32, orgy = (int64_t)y0 << 32;
+    const size_t n_det = (size_t)g.ndx * g.ndz;
+    const float two_m32 = 2.3283064365386963e-10f;
+    const unsigned lane4 = (unsigned)min(lane, FLZ - 1) * 4u;      // lanes 61..63 alias the halo plane with zero weight
+
+    for (int ip = wv; ip < n_proj; ip += FZ_WAVES) {               // one wave owns a whole (tile stack, projection)
+        const AdjC &c = pcs[ip];
+        // z: ray iz sits in plane lz = floor(p0z) + iz - z0 with the same fraction for every ray
+        const int p0z_i = (int)(c.fp0[2] >> 32);
+        const float wcz = (float)(unsigned)c.fp0[2] * two_m32, wfz = 1.f - wcz;
+        bool zuse[NZT], ray_ok[NZT];
+        bool any_use = false;
+        const int iz0 = z0 - p0z_i + lane;                             // this lane's ray in the lowest tile; + FTZ per tile
+#pragma unroll
+        for (int k = 0; k < NZT; ++k) {
+            const int izoff = z0 + k * FTZ - p0z_i;
+            zuse[k] = live[k] && !(izoff + FTZ <= 0 || izoff >= g.ndz);   // some ray of this projection floors into the tile's z range
+            any_use |= zuse[k];
+            const int iz = iz0 + k * FTZ;
+            ray_ok[k] = zuse[k] && lane < FTZ && iz >= 0 && iz < g.ndz;     // the last plane of an image is halo only
+        }
+        if (!any_use) continue;
+        // detector rows crossing the tile's x,y footprint (2-D: a linear functional over a rectangle)
+        const float qx = bcx - (float)c.p0[0], qy = bcy - (float)c.p0[1];
+        const float m00 = (float)c.minv[0][0], m01 = (float)c.minv[0][1];
+        const float ixc = m00 * qx + m01 * qy;
+        const float ixr = fabsf(m00) * (0.5f * ATX) + fabsf(m01) * (0.5f * ATY) + 2e-2f;
+        const int ix_lo = max(0, (int)ceilf(fmaxf(ixc - ixr, -1.f)));
+        const int ix_hi = min(g.ndx - 1, (int)floorf(fminf(ixc + ixr, (float)g.ndx)));
+        if (ix_lo > ix_hi) continue;
+        const int n_rows_w = ix_hi - ix_lo + 1;
+        const float fp0x = (float)c.p0[0] - (float)x0, fp0y = (float)c.p0[1] - (float)y0;
+        const float fux = (float)c.u[0], fuy = (float)c.u[1], fdx = (float)c.d[0], fdy = (float)c.d[1];
+        int64_t ldx = (int64_t)lane * c.fd[0], ldy = (int64_t)lane * c.fd[1];   // sample `lane` of a chunk, relative to its first
+        int64_t k_fux = c.fu[0], k_fuy = c.fu[1], k_fdx = c.fd[0], k_fdy = c.fd[1];
+        asm volatile("" : "+v"(ldx), "+v"(ldy));                       // see k_tile_flat: keep the row loop's inputs in registers
+        asm volatile("" : "+s"(k_fux), "+s"(k_fuy), "+s"(k_fdx), "+s"(k_fdy));
+        float *const proj_c = proj + (size_t)c.slot * n_det + iz0;
+
+        for (int r0 = 0; r0 < n_rows_w; r0 += 64) {
+            int v_jlo = 0, v_jhi = 0;
+            {
+                const int rix = ix_lo + r0 + lane;
+                const float frix = (float)rix;
+                float t0 = 0.f, t1 = (float)(c.n - 1);
+                {
+                    const float cb = fp0x + frix * fux;
+                    if (fdx != 0.f) {
+                        const float inv = 1.f / fdx, ta = (-2e-2f - cb) * inv, tb = ((float)ATX + 2e-2f - cb) * inv;
+                        t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
+                    } else if (cb < -2e-2f || cb >= (float)ATX + 2e-2f) { t0 = 1.f; t1 = 0.f; }
+                }
+                {
+                    const float cb = fp0y + frix * fuy;
+                    if (fdy != 0.f) {
+                        const float inv = 1.f / fdy, ta = (-2e-2f - cb) * inv, tb = ((float)ATY + 2e-2f - cb) * inv;
+                        t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
+                    } else if (cb < -2e-2f || cb >= (float)ATY + 2e-2f) { t0 = 1.f; t1 = 0.f; }
+                }
+                if (rix <= ix_hi && t0 <= t1) {
+                    v_jlo = max(0, (int)ceilf(t0));
+                    v_jhi = min(c.n, (int)floorf(t1) + 1);
+                }
+            }
+            const int r_end = min(64, n_rows_w - r0);
+            int64_t rbx = c.fp0[0] + (int64_t)(ix_lo + r0) * k_fux - orgx, rby = c.fp0[1] + (int64_t)(ix_lo + r0) * k_fuy - orgy;
+            float *pr = proj_c + (size_t)(ix_lo + r0) * g.ndz;
+            for (int r = 0; r < r_end; ++r, rbx += k_fux, rby += k_fuy, pr += g.ndz) {
+                const int jlo = __builtin_amdgcn_readlane(v_jlo, r), jhi = __builtin_amdgcn_readlane(v_jhi, r);
+                if (jhi <= jlo) continue;
+                float S[NZT];
+#pragma unroll
+                for (int k = 0; k < NZT; ++k) S[k] = 0.f;
+                for (int jc = jlo; jc < jhi; jc += 60) {
+                    // one lane per SAMPLE: cell, ownership in x,y and the four x,y weights of sample jc + lane
+                    const int64_t px = (rbx + (int64_t)jc * k_fdx) + ldx, py = (rby + (int64_t)jc * k_fdy) + ldy;
+                    const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32);
+                    const bool own = (lx | ly) < (unsigned)ATX && jc + lane < jhi && lane < 60;
+                    const unsigned t_e = (__umul24(lx, ALY * FLZ) + __umul24(ly, FLZ)) * 4u;
+                    const float wx = (float)(unsigned)px * two_m32, wy = (float)(unsigned)py * two_m32;
+                    const float t_w11 = wx * wy, t_w10 = wx - t_w11, t_w01 = wy - t_w11, t_w00 = 1.f - wx - t_w01;
+                    // compact the owned samples to lanes 0 .. n_own-1 IN REGISTERS (ds_permute: lane i sends to its rank among the
+                    // owned; the others send to lane 63, which is never read: n_own <= 60, and in practice a row owns <= 24
+                    // samples of a 16 x 16 tile; destination lanes nobody writes receive 0 = entries without effect).  The
+                    // sample loop then broadcasts an entry with v_readlane: LDS cycles go to the image reads only (a table entry
+                    // read from LDS cost 6.4 of the 16 LDS cycles per sample, tools/lds_read_bench.hip).
+                    const unsigned long long om = __ballot(own);
+                    const int n_own = (int)__builtin_popcountll(om);
+                    const int dst4 = own ? 4 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(om >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)om, 0u)) : 4 * 63;
+                    const int c_e = __builtin_amdgcn_ds_permute(dst4, (int)t_e);
+                    const int c_w00 = __builtin_amdgcn_ds_permute(dst4, __float_as_int(t_w00)), c_w01 = __builtin_amdgcn_ds_permute(dst4, __float_as_int(t_w01));
+                    const int c_w10 = __builtin_amdgcn_ds_permute(dst4, __float_as_int(t_w10)), c_w11 = __builtin_amdgcn_ds_permute(dst4, __float_as_int(t_w11));
+                    f32x2 Sa[NZT], Sb[NZT];
+#pragma unroll
+                    for (int k = 0; k < NZT; ++k) { Sa[k] = (f32x2){0.f, 0.f}; Sb[k] = (f32x2){0.f, 0.f}; }
+                    // an entry's five readlanes serve every image; (q[0], q[FLZ]) arrive as a register pair from one
+                    // ds_read2st64 and the weights as SGPR pairs: two packed FMAs per sample and image.  Which images take part
+                    // is decided outside the loop (an all-zero or out-of-range image is skipped).
+#define FZ_ENTRY(T, J)                                                                                                      \
+                        const unsigned T##e = (unsigned)__builtin_amdgcn_readlane(c_e, (J)) + lane4;                        \
+                        const f32x2 T##0 = {__int_as_float(__builtin_amdgcn_readlane(c_w00, (J))), __int_as_float(__builtin_amdgcn_readlane(c_w01, (J)))}; \
+                        const f32x2 T##1 = {__int_as_float(__builtin_amdgcn_readlane(c_w10, (J))), __int_as_float(__builtin_amdgcn_readlane(c_w11, (J)))};
+#define FZ_READ(T, K)                                                                                                       \
+                            const float *T##q = (const float *)((const char *)&img[0][0] + (T##e + (unsigned)(K) * (unsigned)(ALX * ALY * FLZ * 4))); \
+                            const f32x2 T##v0 = {T##q[0], T##q[FLZ]}, T##v1 = {T##q[ALY * FLZ], T##q[ALY * FLZ + FLZ]};
+#define FZ_SAMPLE_LOOP(K0, K1)                                                                                              \
+                    for (int jj = 0; jj < n_own; ++jj) { /* one entry per trip: pairs measured the same, fours 6 % slower */ \
+                        FZ_ENTRY(s0_, jj)                                                                                   \
+                        _Pragma("unroll") for (int k = (K0); k < (K1); ++k) {                                               \
+                            FZ_READ(s0_, k)                                                                                 \
+                            Sa[k] += s0_0 * s0_v0; Sb[k] += s0_1 * s0_v1;                                                   \
+                        }                                                                                                   \
+                    }
+                    if (NZT == 2 && zuse[0] && zuse[NZT - 1]) { FZ_SAMPLE_LOOP(0, NZT) }
+                    else if (zuse[0]) { FZ_SAMPLE_LOOP(0, 1) }
+                    else { FZ_SAMPLE_LOOP(NZT - 1, NZT) }
+#undef FZ_SAMPLE_LOOP
+#undef FZ_READ
+#undef FZ_ENTRY
+#pragma unroll
+                    for (int k = 0; k < NZT; ++k) {
+                        const f32x2 St = Sa[k] + Sb[k];
+                        S[k] += St.x + St.y;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NZT; ++k) {
+                    if (!zuse[k]) continue;
+                    const float Sp1 = __shfl_down(S[k], 1, 64);                // plane lane+1
+                    if (ray_ok[k]) atomicAdd(pr + k * FTZ, wfz * S[k] + wcz * Sp1);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // GATHER-form adjoint for untilted unit lattices (the poses of a plain parallel-beam scan: alpha = beta = 0, detector pitch =
 // step = voxel; any phi, translation, COR shift).  For such a lattice the adjoint separates:
 //     (A^T y)(X, Y, Z) = sum_ix  W(X, Y, ix) * Yz(ix, Z)
@@ -1612,9 +1782,15 @@ extern "C" int tomo_forward(tomo_ctx *ctx, const double *h_poses, int n_proj, co
         if (ok) {
             const AdjC *d_c = (const AdjC *)ctx->d_stage;
             TOMO_HIP(ctx, hipMemsetAsync(d_proj, 0, n_det * (size_t)n_proj * sizeof(float), ctx->stream));
-            if (n_flat > 0)
-                TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_tile_flat<true>, tile_grid(g, FTZ), dim3(ADJ_WAVES * 64), 0, d_c, n_flat, d_proj,
-                            (float *)d_vol, g, (const unsigned *)nullptr, 1.f, 0);
+            if (n_flat > 0) {
+                const dim3 fg = tile_grid(g, FTZ);
+                if (fg.x >= 2 && ctx->fwd_flat_ztiles >= 2)         // two z-adjacent tiles per work-group share the per-row set-up
+                    TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_fwd_flat_z<2>, dim3((fg.x + 1) / 2, fg.y, fg.z), dim3(FZ_WAVES * 64), 0, d_c, n_flat,
+                                d_proj, d_vol, g);
+                else
+                    TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_tile_flat<true>, fg, dim3(ADJ_WAVES * 64), 0, d_c, n_flat, d_proj,
+                                (float *)d_vol, g, (const unsigned *)nullptr, 1.f, 0);
+            }
             if (n_proj > n_flat)
                 TOMO_LAUNCH(ctx, "k_fwd_tile", k_tile<true>, grid, dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, d_proj, (float *)d_vol,
                             g, (const unsigned *)nullptr, 1.f, 0);
