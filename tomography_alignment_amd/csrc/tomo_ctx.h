@@ -35,6 +35,15 @@ struct tomo_ctx {
     void *h_stage = nullptr;
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
+    // the tile kernels' constants staged last (stage_tile_consts): reused while the same poses come again and nobody else has
+    // used the staging buffers -- the x-slab calls of one pipelined back-projection, forward + back-projection of a solver
+    // iteration, every iteration of a solver (a re-stage drains the stream: the GPU would idle between slab kernels)
+    bool tile_cache_valid = false;
+    std::vector<double> tile_cache_poses;
+    int tile_cache_opts = 0, tile_cache_nflat = 0, tile_cache_ngather = 0;
+    bool tile_cache_ok = false;
+    double tile_cache_wb = 2.0;
+    size_t tile_cache_gfoff = 0;
     // reduction scratch
     double *d_red = nullptr;
     double *h_red = nullptr;

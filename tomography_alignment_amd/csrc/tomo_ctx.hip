@@ -148,6 +148,7 @@ extern "C" int tomo_set_option(tomo_ctx *ctx, const char *key, int value)
 
 int tomo_ensure_stage(tomo_ctx *ctx, size_t bytes)
 {
+    ctx->tile_cache_valid = false;                       // whoever asks for the staging buffers is about to overwrite them
     if (bytes <= ctx->stage_bytes) return TOMO_OK;
     TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
@@ -181,6 +182,7 @@ extern "C" int tomo_set_geometry(tomo_ctx *ctx, const tomo_geom *g)
     if (!ctx || !g) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
     if (g->nx < 1 || g->ny < 1 || g->nz < 1 || g->ndx < 1 || g->ndz < 1 || !(g->step > 0.0) || !(g->det_y > g->src_y))
         return tomo_fail(ctx, TOMO_ERR_ARG, "set_geometry: non-positive shape/step or det_y <= src_y");
+    ctx->tile_cache_valid = false;
     TomoGeomC c{};
     c.nx = g->nx; c.ny = g->ny; c.nz = g->nz; c.ndx = g->ndx; c.ndz = g->ndz;
     c.nxp = g->nx + 2 * TOMO_HALO; c.nyp = g->ny + 2 * TOMO_HALO; c.nzp = g->nz + 2 * TOMO_HALO;

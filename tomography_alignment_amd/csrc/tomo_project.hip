@@ -1694,6 +1694,17 @@ static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, b
     *weight_bound = 2.0;
     *n_flat = 0;
     if (n_gather) *n_gather = 0;
+    const int opts = (ctx->tile_flat != 0 ? 1 : 0) | (ctx->adj_flat_gather != 0 ? 2 : 0);
+    const size_t n_pose_doubles = (size_t)n_proj * TOMO_POSE_STRIDE;
+    if (ctx->tile_cache_valid && ctx->tile_cache_opts == opts && ctx->tile_cache_poses.size() == n_pose_doubles && n_proj > 0 &&
+        memcmp(ctx->tile_cache_poses.data(), h_poses, n_pose_doubles * sizeof(double)) == 0) {
+        *all_ok = ctx->tile_cache_ok;                    // same poses, staging buffers untouched since: nothing to do
+        *weight_bound = ctx->tile_cache_wb;
+        *n_flat = ctx->tile_cache_nflat;
+        if (n_gather) *n_gather = ctx->tile_cache_ngather;
+        if (d_gfc) *d_gfc = (const GfC *)((char *)ctx->d_stage + ctx->tile_cache_gfoff);
+        return TOMO_OK;
+    }
     TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const size_t gf_off = (sizeof(AdjC) * (size_t)std::max(n_proj, 1) + 255) & ~(size_t)255;
     int rc = tomo_ensure_stage(ctx, gf_off + sizeof(GfC) * (size_t)std::max(n_proj, 1));
@@ -1730,7 +1741,7 @@ static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, b
         // and three consecutive samples cover a voxel's footprint (2 * (|m_r0| + |m_r1| + 5e-3) < 3) -- true for detector
         // pitch = step = voxel at any phi (sum <= sqrt 2)
         const double ea = fabs(a.minv[0][0]) + fabs(a.minv[0][1]), eb = fabs(a.minv[2][0]) + fabs(a.minv[2][1]);
-        const bool gatherable = untilted && n_gather && ctx->adj_flat_gather != 0 && ea < 1.45 && eb < 1.49 &&      // ea: see GROWS
+        const bool gatherable = untilted && ctx->adj_flat_gather != 0 && ea < 1.45 && eb < 1.49 &&      // ea: see GROWS
                                 fabs(a.minv[0][2]) < 1e-9 && fabs(a.minv[2][2]) < 1e-9;
         if (gatherable) {
             GfC q;
@@ -1757,6 +1768,14 @@ static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, b
     if (d_gfc) *d_gfc = (const GfC *)((char *)ctx->d_stage + gf_off);
     if (n_proj) TOMO_HIP(ctx, hipMemcpyAsync(ctx->d_stage, h, gf_off + sizeof(GfC) * gfc.size(), hipMemcpyHostToDevice, ctx->stream));
     *all_ok = true;
+    ctx->tile_cache_poses.assign(h_poses, h_poses + n_pose_doubles);
+    ctx->tile_cache_opts = opts;
+    ctx->tile_cache_ok = true;
+    ctx->tile_cache_wb = *weight_bound;
+    ctx->tile_cache_nflat = *n_flat;
+    ctx->tile_cache_ngather = (int)gath.size();
+    ctx->tile_cache_gfoff = gf_off;
+    ctx->tile_cache_valid = true;
     return TOMO_OK;
 }
 

@@ -57,7 +57,7 @@ class SIRT(_SIRT):
     def _is_root(self):
         return self.my_rank == 0
 
-    n_pipeline_slabs = 4      # x slabs of the back-projection whose all-reduce overlaps the next slab's kernel
+    n_pipeline_slabs = 8      # x slabs of the back-projection whose all-reduce overlaps the next slab's kernel (the last slab's is exposed)
 
     def _backproject_scaled(self):
         """recon/sirt_mpi.py:98-103 with the Allreduce pipelined: the volume is x-major, so the back-projection is done in
