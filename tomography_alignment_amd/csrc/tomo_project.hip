@@ -454,8 +454,9 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
                             for (int jj = 0; jj < cnt; ++jj) {
                                 const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32), lz = (unsigned)(pz >> 32);
                                 static_assert(ATX == ATY && (ATX & (ATX - 1)) == 0, "ownership test uses (lx | ly) < ATX");
+                                static_assert(ALY == 17 && ALZ == 64, "cell index is written with shifts");
                                 const bool own = (lx | ly) < (unsigned)ATX && lz < (unsigned)ATZ;
-                                const unsigned e = own ? __umul24(lx, ALY * ALZ) + __umul24(ly, ALZ) + lz : 0u;
+                                const unsigned e = own ? ((((lx << 4) + lx + ly) << 6) + lz) : 0u;      // (lx * ALY + ly) * ALZ + lz without a quarter-rate multiply
                                 const float wx = (float)(unsigned)px * two_m32, wy = (float)(unsigned)py * two_m32, wz = (float)(unsigned)pz * two_m32;
                                 const float *q = img + e;
                                 const f32x2 p00 = {q[0], q[1]}, p01 = {q[ALZ], q[ALZ + 1]};
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
                                     const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
                                     const float a0 = ys * wfx, a1 = ys * wcx;
                                     const float b00 = a0 * wfy, b01 = a0 * wcy, b10 = a1 * wfy, b11 = a1 * wcy;
-                                    int *q = &acc[__umul24(lx, ALY * ALZ) + __umul24(ly, ALZ) + lz];
+                                    int *q = &acc[(((lx << 4) + lx + ly) << 6) + lz];                    // (lx * ALY + ly) * ALZ + lz
                                     atomicAdd(q, cvt_round_i32(b00 * wfz));
                                     atomicAdd(q + 1, cvt_round_i32(b00 * wcz));
                                     atomicAdd(q + ALZ, cvt_round_i32(b01 * wfz));
