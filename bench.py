@@ -192,6 +192,8 @@ def main():
     if not args.no_align:
         del solver
         out["alignment_gradient"] = align_rate(comm, ctx, rank, world, N=min(512, max(32, N // 2)), n_proj=720 if N >= 1024 else max(8, n_proj // 2))
+    if roofline is not None:
+        roofline["measured_d2d_copy_GBps"] = copy_probe(ctx, be)        # read + write of a 2 GiB hipMemcpy D2D, same run
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(be, d_true, N, n_proj, phi)
     if rank == 0:
@@ -246,23 +248,70 @@ def align_rate(comm, ctx, rank, world, N=512, n_proj=720, passes=3):
             "projections_per_launch": int(mine.size), "cost_first": rates["near_truth"][1], "cost_first_at_start": rates["start"][1]}
 
 
+def _cpu_share():
+    """Cores this process may actually use: the cgroup CPU quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(be, d_true, N, n_proj, phi):
-    """Time the CPU oracle (plain-C port of the reference algorithm, serial like the reference's Fortran) on
-    ONE projection angle of the same workload: forward + adjoint; extrapolate linearly to n_proj angles."""
+    """Time the CPU oracle (plain-C port of the reference algorithm) on a bounded sample of the same workload, forward +
+    adjoint, extrapolated linearly in n_proj: (i) ONE thread, like the reference's serial Fortran, on one projection angle;
+    (ii) all host cores (OpenMP over rays) on a few angles."""
     from oracle import oracle as orc
     x = be.download(d_true)
-    og = orc.Geo(1, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
-    ph = np.array([phi[n_proj // 3]])           # a generic (non axis-aligned) angle
-    t0 = time.perf_counter()
-    ax = orc.forward(og, x, phi=ph)
-    t1 = time.perf_counter()
-    orc.adjoint(og, ax.astype(np.float32), phi=ph)
-    t2 = time.perf_counter()
-    per_it = ((t1 - t0) + (t2 - t1)) * n_proj
-    return {"value": round(1.0 / per_it, 8), "unit": "it/s", "cores": 1, "kind": "port",
-            "sample": "1 of %d angles of the same %d^3 workload (forward %.1f s + adjoint %.1f s on one host core), "
-                      "extrapolated linearly in n_proj" % (n_proj, N, t1 - t0, t2 - t1),
-            "host_cpus": os.cpu_count()}
+    lib = orc._lib()
+    n_cpu = _cpu_share()
+
+    def one(n_ang, threads):
+        lib.orc_set_threads(int(threads))
+        og = orc.Geo(n_ang, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
+        ph = phi[n_proj // 3: n_proj // 3 + n_ang]           # generic (non axis-aligned) angles
+        t0 = time.perf_counter()
+        ax = orc.forward(og, x, phi=ph)
+        t1 = time.perf_counter()
+        orc.adjoint(og, ax.astype(np.float32), phi=ph, coloured_rows=threads > 1)     # threads own whole detector rows: no atomics
+        t2 = time.perf_counter()
+        return (t1 - t0) / n_ang, (t2 - t1) / n_ang
+
+    f1, a1 = one(1, 1)
+    out = {"value": round(1.0 / ((f1 + a1) * n_proj), 8), "unit": "it/s", "cores": 1, "kind": "port",
+           "sample": "1 of %d angles of the same %d^3 workload (forward %.1f s + adjoint %.1f s on one host core), "
+                     "extrapolated linearly in n_proj" % (n_proj, N, f1, a1),
+           "host_cpus": os.cpu_count(), "cpu_share": n_cpu}
+    if n_cpu > 1:
+        n_ang = 2 if n_cpu >= 8 else 1
+        fa, aa = one(n_ang, n_cpu)
+        out["all_cores"] = {"value": round(1.0 / ((fa + aa) * n_proj), 8), "unit": "it/s", "cores": n_cpu,
+                            "sample": "%d of %d angles (forward %.2f s + adjoint %.2f s per angle on %d threads, OpenMP over rays)"
+                                      % (n_ang, n_proj, fa, aa, n_cpu)}
+    lib.orc_set_threads(1)
+    return out
+
+
+def copy_probe(ctx, be, n_bytes=1 << 31):
+    """Measured device-to-device copy rate (read + write bytes per second) -- the practical ceiling next to the 8 TB/s spec."""
+    n = n_bytes // 4
+    a, b = be.zeros(n), be.empty(n)
+    b.copy_from(a)
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(4):
+        b.copy_from(a)
+    ms = ctx.timer_stop()
+    return round(4 * 2.0 * n_bytes / (ms * 1e-3) / 1e9, 1)
 
 
 if __name__ == "__main__":

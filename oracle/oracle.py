@@ -239,15 +239,21 @@ def forward(geo, rec, alpha=None, beta=None, phi=None, xyz_shift=None):
     return out
 
 
-def adjoint(geo, y, alpha=None, beta=None, phi=None, xyz_shift=None):
+def adjoint(geo, y, alpha=None, beta=None, phi=None, xyz_shift=None, coloured_rows=False):
+    """coloured_rows=True: the atomic-free multi-thread form (orc_adjoint_rows; detector pitch >= voxel only) -- used by
+    bench.py's all-cores timing, same sums."""
     n_proj, alpha, beta, phi, xyz_shift = _default_poses(geo, alpha, beta, phi, xyz_shift)
     nx, ny, nz = (int(v) for v in geo.vox_shape)
     y = np.ascontiguousarray(y, dtype=np.float32).reshape(n_proj, geo.n_det)
     vol = np.zeros(geo.n_vox, np.float64)
     for ip in range(n_proj):
         p0, rhat, n, _, _, _ = ray_setup(geo, alpha[ip], beta[ip], phi[ip], xyz_shift[ip], geo.cor_shift[ip])
-        _lib().orc_adjoint(_p(p0), _p(rhat), ctypes.c_int64(geo.n_det), n, ctypes.c_double(geo.step_size),
-                           nx, ny, nz, _p(y[ip]), _p(vol))
+        if coloured_rows:
+            _lib().orc_adjoint_rows(_p(p0), _p(rhat), ctypes.c_int64(geo.n_det), ctypes.c_int64(int(geo.det_shape[1])), n,
+                                    ctypes.c_double(geo.step_size), nx, ny, nz, _p(y[ip]), _p(vol))
+        else:
+            _lib().orc_adjoint(_p(p0), _p(rhat), ctypes.c_int64(geo.n_det), n, ctypes.c_double(geo.step_size),
+                               nx, ny, nz, _p(y[ip]), _p(vol))
     return vol
 
 
