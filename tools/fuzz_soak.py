@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""Run tests/test_gpu_fuzz.py's cross-check over many seeds (development aid): python tools/fuzz_soak.py [first] [last]"""
+import os
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_fuzz as f      # noqa: E402
+
+a, b = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4, 40)
+for seed in range(a, b):
+    f.test_tile_kernels_agree_with_ray_driven_kernels(seed)
+print("seeds %d..%d ok" % (a, b - 1))
