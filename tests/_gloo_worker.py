@@ -33,8 +33,22 @@ def main(out_path):
     n_allreduce_sirt = comm.n_vol_allreduce
     c = cgls_mpi.CGLS(comm, geo, g["b"].copy(), angles, g["xyz"], options={"_backend": OracleBackend(shard)})
     crec, cerr = c.run_main_iteration(niter=4)
+    # sharded alignment: projections split over the ranks, replicated volume, one table all-reduce at the end
+    from oracle import oracle as orc
+    from tomography_alignment_amd import alignment
+    Na, na = 16, 4
+    xa = orc.shepp3d(Na).astype(np.float32)
+    phia = np.array([0.4, 1.1, 1.9, 2.6])
+    true = np.column_stack([[0.8, -0.5, 0.3, -0.9], [-0.4, 0.7, -0.6, 0.2], np.deg2rad([0.5, -0.4, 0.3, -0.2]), np.deg2rad([-0.3, 0.2, 0.4, -0.5])])
+    oga = orc.Geo(1, np.array([Na] * 3), np.ones(3), np.array([Na, Na]), np.ones(2))
+    ba = np.array([orc.projection_gradient(oga, xa, true[i, 2], true[i, 3], phia[i], np.array([true[i, 0], 0., true[i, 1]]), np.zeros(3))[0]
+                   for i in range(na)])
+    geoa = Geometry(na, np.array([Na] * 3), np.ones(3), np.array([Na, Na]), np.ones(2))
+    bounds = ((-3., 3.), (-3., 3.), (-0.02, 0.02), (-0.02, 0.02))
+    ares = alignment.align_projections_sharded(comm, OracleBackend(geoa), xa, ba, phia, letters="xzab", bounds=bounds)
     if comm.rank == 0:
-        np.savez(out_path, rec=rec, err=err, crec=crec, cerr=cerr, n_allreduce_sirt=n_allreduce_sirt, cor=cor)
+        np.savez(out_path, rec=rec, err=err, crec=crec, cerr=cerr, n_allreduce_sirt=n_allreduce_sirt, cor=cor,
+                 align_x=ares["x"], align_fun=ares["fun"], align_true=true, align_nfev=ares["nfev"])
     dist.barrier()
     dist.destroy_process_group()
 

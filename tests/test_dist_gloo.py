@@ -43,6 +43,9 @@ def test_sharded_solvers_match_unsharded(tmp_path):
     assert np.allclose(two["cerr"], one["cerr"], rtol=1e-4)
     # one all-reduce of V at init (recon/sirt_mpi.py:68) + one per iteration (:103)
     assert int(two["n_allreduce_sirt"]) == 1 + len(two["err"])
+    # sharded alignment: every rank aligns its block, the gathered table is the unsharded answer and recovers the poses
+    assert np.allclose(two["align_x"], one["align_x"], atol=1e-9) and np.array_equal(two["align_nfev"], one["align_nfev"])
+    assert np.allclose(two["align_x"], two["align_true"], atol=2e-4) and np.all(two["align_fun"] < 1e-6)
 
 
 def test_angle_split_is_the_reference_split():
