@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--perturbed", action="store_true", help="alpha,beta ~ U(+-1 deg), tx,tz ~ U(+-2 px) (default_rng(0))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-align", action="store_true", help="skip the alignment-gradient evals/s side measurement (config 5)")
+    ap.add_argument("--no-tilted", action="store_true", help="skip the tilted-pose SIRT side measurement")
     ap.add_argument("--force-sharded", action="store_true",
                     help="N=1 only: run the multi-GPU code path (sharded solver, x-slab pipelined all-reduce) on a 1-rank RCCL communicator")
     ap.add_argument("--fwd-variant", type=int, default=None)
@@ -189,6 +190,30 @@ def main():
         step_alg = n_proj * (12.0 * N ** 3 + 8.0 * n_det) + 16.0 * n_proj * n_det + 16.0 * N ** 3
         out["sirt_step_alg_GBps"] = round(step_alg / (elapsed / args.steps) / 1e9, 1)
 
+    if not args.no_tilted and not args.perturbed:
+        # side measurement (not `value`): the same workload with tilted poses (alpha, beta ~ U(+-1 deg), tx, tz ~ U(+-2 px),
+        # default_rng(0) -- SURVEY 8d's perturbed run): these take the general tile kernels, which is what SIRT runs on
+        # once an alignment pass has moved the poses
+        del solver
+        rng = np.random.default_rng(0)
+        alpha_t, beta_t = np.deg2rad(rng.uniform(-1, 1, n_proj)), np.deg2rad(rng.uniform(-1, 1, n_proj))
+        xyz_t = np.zeros((n_proj, 3))
+        xyz_t[:, 0], xyz_t[:, 2] = rng.uniform(-2, 2, n_proj), rng.uniform(-2, 2, n_proj)
+        angles_t = np.array([phi, alpha_t, beta_t]).T
+        poses_t = _lib.poses_array(phi[my_rows], alpha_t[my_rows], beta_t[my_rows], xyz_t[my_rows], np.zeros(3))
+        be.forward(poses_t, d_true, d_b)
+        if world > 1 or args.force_sharded:
+            solver = sirt_mpi.SIRT(comm, geo, d_b, angles_t, xyz_t, opts)
+        else:
+            solver = sirt_mod.SIRT(geo, d_b, angles_t, xyz_t, opts)
+        solver.iterate_device(niter=1)
+        barrier()
+        t0 = time.perf_counter()
+        solver.iterate_device(niter=2)
+        barrier()
+        dt = comm.allreduce_max(time.perf_counter() - t0)
+        out["tilted_poses"] = {"value": round(2.0 / dt, 6), "unit": "it/s", "steps": 2, "warmup": 1,
+                               "config": "same workload, alpha, beta ~ U(+-1 deg), tx, tz ~ U(+-2 px): general tile kernels"}
     if not args.no_align:
         del solver
         out["alignment_gradient"] = align_rate(comm, ctx, rank, world, N=min(512, max(32, N // 2)), n_proj=720 if N >= 1024 else max(8, n_proj // 2))
