@@ -939,6 +939,7 @@ struct GfC {
     int32_t n, zc, slot;
 };
 
+template <int NJ>      // samples per row that can reach a column: 3 for step >= 0.95 voxel, 6 for step >= 0.475
 __global__ __launch_bounds__(GWAVES * 64) void k_adj_gather_flat(const GfC *__restrict__ cs, int n_proj, const float *__restrict__ proj,
                                                                  float *__restrict__ vol, TomoGeomC g, int xs, int xe)
 {
@@ -961,8 +962,9 @@ __global__ __launch_bounds__(GWAVES * 64) void k_adj_gather_flat(const GfC *__re
 
     // ---- 1. the weight table of this lane's column for projection IPX -> wtab[GRP % 3][IPX % GWAVES][lane].  The table does not
     //         depend on z: the four waves share it, wave w computes the projections 4 g + w (one barrier per four projections).
-    //   candidates: rows i0..i0+2, samples j0..j0+2 (the footprint |dx|,|dy| < 1 maps to |d ix| <= |m00|+|m01| < 1.5, likewise
-    //   for j: three consecutive integers cover an interval shorter than 3); W_k from exact 32.32 positions relative to the voxel
+    //   candidates: rows i0..i0+2, samples j0..j0+NJ-1 (the footprint |dx|,|dy| < 1 maps to |d ix| <= |m00|+|m01| < 1.5: three
+    //   consecutive integers cover an interval shorter than 3; likewise |d j| <= |m10|+|m11| < NJ/2); W_k from exact 32.32
+    //   positions relative to the voxel
 #define G_TABLE(IPX)                                                                                                       \
     {                                                                                                                      \
         float4 t4 = {0.f, 0.f, 0.f, 0.f};                                                                                  \
@@ -978,7 +980,7 @@ __global__ __launch_bounds__(GWAVES * 64) void k_adj_gather_flat(const GfC *__re
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                                \
                 int64_t sx = rx, sy = ry;                                                                                  \
                 float wsum = 0.f;                                                                                          \
-                _Pragma("unroll") for (int mth = 0; mth < 3; ++mth) {                                                      \
+                _Pragma("unroll") for (int mth = 0; mth < NJ; ++mth) {                                                     \
                     const int hx = (int)(sx >> 32), hy = (int)(sy >> 32);                                                  \
                     const float fx = (float)(unsigned)sx * two_m32, fy = (float)(unsigned)sy * two_m32;                    \
                     const float wx = hx == 0 ? 1.f - fx : (hx == -1 ? fx : 0.f); /* tent on [-1, 1) */                     \
@@ -1712,6 +1714,7 @@ static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, b
     if (rc) return rc;
     std::vector<AdjC> gath, flat, gen;
     std::vector<GfC> gfc;
+    double eb_max = 0.0;
     for (int i = 0; i < n_proj; ++i) {
         ProjC pc;
         tomo_make_projc(g, h_poses + (size_t)i * TOMO_POSE_STRIDE, pc, nullptr);
@@ -1742,7 +1745,7 @@ static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, b
         // and three consecutive samples cover a voxel's footprint (2 * (|m_r0| + |m_r1| + 5e-3) < 3) -- true for detector
         // pitch = step = voxel at any phi (sum <= sqrt 2)
         const double ea = fabs(a.minv[0][0]) + fabs(a.minv[0][1]), eb = fabs(a.minv[2][0]) + fabs(a.minv[2][1]);
-        const bool gatherable = untilted && ctx->adj_flat_gather != 0 && ea < 1.45 && eb < 1.49 &&      // ea: see GROWS
+        const bool gatherable = untilted && ctx->adj_flat_gather != 0 && ea < 1.45 && eb < 2.99 &&      // ea: see GROWS; eb: NJ <= 6
                                 fabs(a.minv[0][2]) < 1e-9 && fabs(a.minv[2][2]) < 1e-9;
         if (gatherable) {
             GfC q;
@@ -1754,6 +1757,7 @@ static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, b
             q.n = a.n; q.slot = a.slot;
             gath.push_back(a);
             gfc.push_back(q);
+            eb_max = std::max(eb_max, eb);
         } else
             (untilted ? flat : gen).push_back(a);
     }
@@ -1776,6 +1780,7 @@ static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, b
     ctx->tile_cache_nflat = *n_flat;
     ctx->tile_cache_ngather = (int)gath.size();
     ctx->tile_cache_gfoff = gf_off;
+    ctx->tile_cache_eb_max = eb_max;
     ctx->tile_cache_valid = true;
     return TOMO_OK;
 }
@@ -1880,7 +1885,10 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
         const int xs = std::max(0, ATX * xt0 - 1), xe = (xt1 == n_xt) ? g.nx : std::min(g.nx, ATX * xt1 - 1);
         if (xe > xs) {
             const dim3 ggrid((g.nz + 64 * GWAVES - 1) / (64 * GWAVES), (g.ny + GTY - 1) / GTY, (xe - xs + GTX - 1) / GTX);
-            TOMO_LAUNCH(ctx, "k_adj_gather_flat", k_adj_gather_flat, ggrid, dim3(GWAVES * 64), 0, d_gfc, n_gather, d_proj, d_vol, g, xs, xe);
+            if (ctx->tile_cache_eb_max < 1.49)
+                TOMO_LAUNCH(ctx, "k_adj_gather_flat", k_adj_gather_flat<3>, ggrid, dim3(GWAVES * 64), 0, d_gfc, n_gather, d_proj, d_vol, g, xs, xe);
+            else        // finer sampling along the rays (step down to ~0.475 voxel): six samples per row can reach a column
+                TOMO_LAUNCH(ctx, "k_adj_gather_flat", k_adj_gather_flat<6>, ggrid, dim3(GWAVES * 64), 0, d_gfc, n_gather, d_proj, d_vol, g, xs, xe);
         }
     }
     if (n_proj == n_gather) return TOMO_OK;
