@@ -1,0 +1,495 @@
+// kernels_grad.hip.h -- projection + 6-DoF pose gradient kernels (plain, dword-gather, DPP neighbour-shift), optionally fused with the residual reduction
+// Part of the single translation unit tomo_project.hip (included there, in this order: kernels_ray, kernels_tile,
+// kernels_grad); not compiled on its own.
+
+// ------------------------------------------------------------------------------------------------
+// projection + 6-DoF pose gradient.  Per sample only the interpolant's spatial gradient is formed
+// (3 values); S0 = sum_j grad_j and S1 = sum_j sf_j*grad_j are accumulated and the per-ray 9x3 pose
+// Jacobian is applied once (same algebra as src/ray_wt_grad.f90:136-149).
+// FUSED: multiply by the residual and reduce to 7 numbers per projection.
+// ------------------------------------------------------------------------------------------------
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_proj_grad(const ProjC *__restrict__ pcs, const GradC *__restrict__ gcs,
+                                                   const float *__restrict__ vp, float *__restrict__ proj,
+                                                   float *__restrict__ grad, const float *__restrict__ bvec,
+                                                   float *__restrict__ resid, double *__restrict__ red, TomoGeomC g,
+                                                   int row_order)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ix = blockIdx.y * 4 + wv, ip = blockIdx.z;
+    int iz = blockIdx.x * 64 + lane;
+    const bool valid = (ix < g.ndx) && (iz < g.ndz);
+    const int ixc = min(ix, g.ndx - 1);
+    if (iz >= g.ndz) iz = g.ndz - 1;
+    const ProjC &c = pcs[ip];
+    const GradC &gc = gcs[ip];
+    RayCtx r;
+    ray_setup(c, g, ixc, iz, valid, r);
+    const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
+    const int64_t sy = g.nzp, sx = (int64_t)g.nyp * g.nzp;
+    const float sfs = (float)(g.step / c.rlen);      // sf_j = (j*step)/|r_0|   ray_voxel_utilities.py:151
+    double val = 0.0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
+    for (int jb = r.j0; jb < r.j1; jb += TOMO_JB) {
+        int ia[3];
+        float f0[3];
+        tomo_block_anchor(r.b, r.d, jb, ia, f0);
+        const float *base = vp + ((int64_t)(ia[0] + TOMO_HALO) * sx + (int64_t)(ia[1] + TOMO_HALO) * sy + (ia[2] + TOMO_HALO));
+        const int cnt = min(TOMO_JB, r.j1 - jb);
+        float av = 0.f, a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float t = (float)jj;
+            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
+            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+            const float wx = x - fx, wy = y - fy, wz = z - fz;
+            const float *q = base + ((int64_t)(int)fx * sx + (int64_t)(int)fy * sy + (int)fz);
+            const float v000 = q[0], v001 = q[1], v010 = q[sy], v011 = q[sy + 1];
+            const float v100 = q[sx], v101 = q[sx + 1], v110 = q[sx + sy], v111 = q[sx + sy + 1];
+            const float d00 = v001 - v000, d01 = v011 - v010, d10 = v101 - v100, d11 = v111 - v110;
+            const float c00 = fmaf(wz, d00, v000), c01 = fmaf(wz, d01, v010), c10 = fmaf(wz, d10, v100), c11 = fmaf(wz, d11, v110);
+            const float dz0 = fmaf(wy, d01 - d00, d00), dz1 = fmaf(wy, d11 - d10, d10);
+            const float gz = fmaf(wx, dz1 - dz0, dz0);
+            const float dy0 = c01 - c00, dy1 = c11 - c10;
+            const float e0 = fmaf(wy, dy0, c00), e1 = fmaf(wy, dy1, c10);
+            const float gy = fmaf(wx, dy1 - dy0, dy0);
+            const float gx = e1 - e0;
+            av += fmaf(wx, gx, e0);
+            const float sf = (float)(jb + jj) * sfs;
+            a0x += gx; a0y += gy; a0z += gz;
+            a1x = fmaf(sf, gx, a1x); a1y = fmaf(sf, gy, a1y); a1z = fmaf(sf, gz, a1z);
+        }
+        val += (double)av;
+        s0[0] += (double)a0x; s0[1] += (double)a0y; s0[2] += (double)a0z;
+        s1[0] += (double)a1x; s1[1] += (double)a1y; s1[2] += (double)a1z;
+    }
+    // per-ray pose Jacobian (utilities/ray_voxel_utilities.py:38-49)
+    const double s[3] = {gc.s00[0] + ixc * gc.sdx, gc.s00[1], gc.s00[2] + iz * gc.sdz};
+    double qv[3], gk[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) qv[a] = gc.ry[a][0] * s[0] + gc.ry[a][1] * s[1] + gc.ry[a][2] * s[2] + gc.t[a];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gk[k] = gc.rzx[0][k] * s0[0] + gc.rzx[1][k] * s0[1] + gc.rzx[2][k] * s0[2];
+    gk[3] = gk[4] = gk[5] = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double d3 = gc.a3[a][0] * qv[0] + gc.a3[a][1] * qv[1] + gc.a3[a][2] * qv[2];
+        const double d4 = gc.a4[a][0] * qv[0] + gc.a4[a][1] * qv[1] + gc.a4[a][2] * qv[2];
+        const double d5 = gc.a5[a][0] * s[0] + gc.a5[a][1] * s[1] + gc.a5[a][2] * s[2];
+        gk[3] += d3 * s0[a] + gc.app[0][a] * s1[a];
+        gk[4] += d4 * s0[a] + gc.app[1][a] * s1[a];
+        gk[5] += d5 * s0[a] + gc.app[2][a] * s1[a];
+    }
+    const size_t n_det = (size_t)g.ndx * g.ndz;
+    const size_t ray = (size_t)ixc * g.ndz + iz;
+    if (!FUSED) {
+        if (valid) {
+            proj[ray] = (float)val;
+            if (row_order == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) grad[k * n_det + ray] = (float)gk[k];
+            } else {   // tx,ty,tz,alpha,beta,phi  (src/external_forward_projection.f90:56-69)
+                grad[0 * n_det + ray] = (float)gk[0]; grad[1 * n_det + ray] = (float)gk[1]; grad[2 * n_det + ray] = (float)gk[2];
+                grad[3 * n_det + ray] = (float)gk[4]; grad[4 * n_det + ray] = (float)gk[5]; grad[5 * n_det + ray] = (float)gk[3];
+            }
+        }
+    } else {
+        double part[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (valid) {
+            const float pv = (float)val;                                  // projection_operators.py:119 cast
+            const double res = (double)(bvec[(size_t)gc.b_row * n_det + ray] - pv);   // alignment_functions.py:23
+            if (resid) resid[(size_t)gc.slot * n_det + ray] = (float)res;
+            part[0] = 0.5 * res * res;                                    // :124
+#pragma unroll
+            for (int k = 0; k < 6; ++k) part[1 + k] = -(double)(float)gk[k] * res;   // :35,146
+        }
+        __shared__ double sh[4][7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const double w = wave_sum_d(part[k]);
+            if (lane == 0) sh[wv][k] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x < 7) {
+            const int k = threadIdx.x;
+            atomicAdd(&red[(size_t)gc.slot * 7 + k], sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// projection + gradient, variant 2: the same sums as k_proj_grad with a cheaper sample (about 40 VALU instead of 59).
+//   * addressing as in k_fwd_v2: the sample blocks are walked in wave-uniform steps, the block bases are SGPR pairs and each
+//     lane carries ONE 32-bit byte offset for all eight corners (saddr + voffset loads): 3 integer ops instead of 14 64-bit ones;
+//   * eight dword gathers instead of four dwordx2 (see the note in the kernel: 3.5x cheaper in the L1 pipeline);
+//   * the lerps are written on (z, z+1) register pairs -- y first, then x, then z -- so that they map 1:1 onto
+//     v_pk_add_f32 / v_pk_fma_f32 without register shuffles.
+// (A version that loaded only the four lower-z corners and took the upper ones from the neighbouring lane by a lane shift was
+// measured 30 % SLOWER than variant 1: the kernel is VALU-bound, not gather-bound, and the shifts cost more than the loads.)
+// Only lanes inside their own [lo, hi) execute loads, all at addresses of samples inside the padded volume.
+// ------------------------------------------------------------------------------------------------
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ pcs, const GradC *__restrict__ gcs,
+                                                      const float *__restrict__ vp, float *__restrict__ proj,
+                                                      float *__restrict__ grad, const float *__restrict__ bvec,
+                                                      float *__restrict__ resid, double *__restrict__ red, TomoGeomC g,
+                                                      int row_order)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Grid = (ix groups, projections, detector-z chunks), z chunk SLOWEST: all projections of one 64-row detector slab run
+    // back to back, so the volume slab they read (n^2 * 64 cells, 64 MB at 512^3) stays in the 256 MB Infinity Cache
+    // instead of the whole volume streaming from HBM once per projection.  Workgroups are dealt to the 8 XCDs round-robin
+    // in dispatch order, so the swizzle gives each XCD a contiguous range of ix groups (neighbouring rays share L2 lines).
+    // (Volumes that fit the cache anyway keep the plain order row_order < 16: z chunk fastest, projection slowest.)
+    int ix, ip, iz;
+    if (row_order & 16) {
+        const int nxg = gridDim.x;
+        const int xg = ((nxg & 7) == 0) ? ((int)(blockIdx.x & 7) * (nxg >> 3) + (int)(blockIdx.x >> 3)) : (int)blockIdx.x;
+        ix = xg * 4 + wv, ip = blockIdx.y, iz = blockIdx.z * 64 + lane;
+    } else {
+        ix = blockIdx.y * 4 + wv, ip = blockIdx.z, iz = blockIdx.x * 64 + lane;
+    }
+    row_order &= 15;
+    const bool valid = (ix < g.ndx) && (iz < g.ndz);
+    const int ixc = min(ix, g.ndx - 1);
+    if (iz >= g.ndz) iz = g.ndz - 1;
+    const ProjC &c = pcs[ip];
+    const GradC &gc = gcs[ip];
+    RayCtx r;
+    ray_setup(c, g, ixc, iz, valid, r);
+    const bool nonempty = r.j1 > r.j0;
+    const int J0 = __builtin_amdgcn_readfirstlane(wave_min_i32(nonempty ? r.j0 : INT_MAX));
+    const int J1 = __builtin_amdgcn_readfirstlane(wave_max_i32(nonempty ? r.j1 : 0));
+    const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
+    const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;
+    const float sfs = (float)(g.step / c.rlen);
+    // Eight DWORD gathers per sample, on purpose: with lanes on consecutive z cells a wave-wide global_load_dword costs
+    // 4.8 cycles of the CU's texture-address/L1 pipeline, a dwordx2 (or x4) 17 (tools/gather_bench.hip), and that pipeline
+    // is what bounds this kernel (TA_BUSY = 100 %, profiles/).  The z + 1 bases are offset by an SGPR the compiler cannot
+    // see through, or it would fuse each (z, z + 1) pair back into one dwordx2.
+    int four;
+    asm volatile("s_mov_b32 %0, 4" : "=s"(four));
+    double val = 0.0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
+    for (int jb = J0; jb < J1; jb += TOMO_JB) {
+        int ia[3];
+        float f0[3];
+        tomo_block_anchor(r.b, r.d, jb, ia, f0);
+        const int64_t lin = ((int64_t)(ia[0] + TOMO_HALO) * g.nyp + (ia[1] + TOMO_HALO)) * g.nzp + (ia[2] + TOMO_HALO);
+        const int64_t lin0 = readfirstlane_i64(lin);
+        const int delta = (int)(lin - lin0);
+        const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(delta));
+        const char *sb00 = (const char *)(vp + (lin0 + m));
+        const char *sb01 = sb00 + sy4;
+        const char *sb10 = sb00 + sx4;
+        const char *sb11 = sb10 + sy4;
+        const char *sc00 = sb00 + four, *sc01 = sb01 + four, *sc10 = sb10 + four, *sc11 = sb11 + four;   // the z + 1 corners
+        const uint32_t off0 = (uint32_t)(delta - m) * 4u;
+        const int lo = max(r.j0, jb) - jb, hi = min(r.j1, jb + TOMO_JB) - jb;      // this lane's samples of the block
+        float av = 0.f;
+        f32x2 a0xy = {0.f, 0.f}, a1xy = {0.f, 0.f}, az = {0.f, 0.f};              // (S0x, S0y), (S1x, S1y), (S0z, S1z)
+        const float sfb = (float)jb * sfs;
+        // two samples per trip: all 16 gathers are issued before the first value is used (the kernel waits on memory 3/4 of
+        // the time; this doubles the loads in flight per wave).  An odd tail re-reads sample A's address and is masked out.
+        for (int jj = lo; jj < hi; jj += 2) {
+            const float ta = (float)jj, tb = ta + 1.f;
+            const bool two = jj + 1 < hi;
+            const float xa = fmaf(ta, dxf, f0[0]), ya = fmaf(ta, dyf, f0[1]), za = fmaf(ta, dzf, f0[2]);
+            const float xb = fmaf(tb, dxf, f0[0]), yb = fmaf(tb, dyf, f0[1]), zb = fmaf(tb, dzf, f0[2]);
+            const float fxa = floorf(xa), fya = floorf(ya), fza = floorf(za);
+            const float fxb = floorf(xb), fyb = floorf(yb), fzb = floorf(zb);
+            const uint32_t voa = off0 + __umul24((uint32_t)(int)fxa, sx4) + __umul24((uint32_t)(int)fya, sy4) + ((uint32_t)(int)fza << 2);
+            const uint32_t vob_ = off0 + __umul24((uint32_t)(int)fxb, sx4) + __umul24((uint32_t)(int)fyb, sy4) + ((uint32_t)(int)fzb << 2);
+            const uint32_t vob = two ? vob_ : voa;
+            const f32x2 a00 = {*(const float *)(sb00 + voa), *(const float *)(sc00 + voa)};
+            const f32x2 a01 = {*(const float *)(sb01 + voa), *(const float *)(sc01 + voa)};
+            const f32x2 a10 = {*(const float *)(sb10 + voa), *(const float *)(sc10 + voa)};
+            const f32x2 a11 = {*(const float *)(sb11 + voa), *(const float *)(sc11 + voa)};
+            const f32x2 b00 = {*(const float *)(sb00 + vob), *(const float *)(sc00 + vob)};
+            const f32x2 b01 = {*(const float *)(sb01 + vob), *(const float *)(sc01 + vob)};
+            const f32x2 b10 = {*(const float *)(sb10 + vob), *(const float *)(sc10 + vob)};
+            const f32x2 b11 = {*(const float *)(sb11 + vob), *(const float *)(sc11 + vob)};
+            {
+                const float wx = xa - fxa, wy = ya - fya, wz = za - fza;
+                const f32x2 dy0 = a01 - a00, dy1 = a11 - a10;          // d/dy on the x = 0 / x = 1 faces, at z and z + 1
+                const f32x2 c0 = a00 + wy * dy0, c1 = a10 + wy * dy1;  // y-lerped
+                const f32x2 dx = c1 - c0;                              // d/dx at z, z + 1
+                const f32x2 e = c0 + wx * dx;                          // x,y-lerped value at z, z + 1
+                const f32x2 dyx = dy0 + wx * (dy1 - dy0);              // d/dy at z, z + 1
+                const float gz = e.y - e.x;
+                const float gx = fmaf(wz, dx.y - dx.x, dx.x), gy = fmaf(wz, dyx.y - dyx.x, dyx.x);
+                av += fmaf(wz, gz, e.x);
+                const float sf = fmaf(ta, sfs, sfb);                   // (jb + jj) * step / |r0|, one rounding
+                const f32x2 gxy = {gx, gy}, one_sf = {1.f, sf};
+                a0xy += gxy;
+                a1xy += sf * gxy;
+                az += one_sf * gz;
+            }
+            {
+                const float keep = two ? 1.f : 0.f;
+                const float wx = xb - fxb, wy = yb - fyb, wz = zb - fzb;
+                const f32x2 dy0 = b01 - b00, dy1 = b11 - b10;
+                const f32x2 c0 = b00 + wy * dy0, c1 = b10 + wy * dy1;
+                const f32x2 dx = c1 - c0;
+                const f32x2 e = c0 + wx * dx;
+                const f32x2 dyx = dy0 + wx * (dy1 - dy0);
+                const float gz = keep * (e.y - e.x);
+                const float gx = keep * fmaf(wz, dx.y - dx.x, dx.x), gy = keep * fmaf(wz, dyx.y - dyx.x, dyx.x);
+                av = fmaf(keep, fmaf(wz, e.y - e.x, e.x), av);
+                const float sf = fmaf(tb, sfs, sfb);
+                const f32x2 gxy = {gx, gy}, one_sf = {1.f, sf};
+                a0xy += gxy;
+                a1xy += sf * gxy;
+                az += one_sf * gz;
+            }
+        }
+        val += (double)av;
+        s0[0] += (double)a0xy.x; s0[1] += (double)a0xy.y; s0[2] += (double)az.x;
+        s1[0] += (double)a1xy.x; s1[1] += (double)a1xy.y; s1[2] += (double)az.y;
+    }
+    const double s[3] = {gc.s00[0] + ixc * gc.sdx, gc.s00[1], gc.s00[2] + iz * gc.sdz};
+    double qv[3], gk[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) qv[a] = gc.ry[a][0] * s[0] + gc.ry[a][1] * s[1] + gc.ry[a][2] * s[2] + gc.t[a];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gk[k] = gc.rzx[0][k] * s0[0] + gc.rzx[1][k] * s0[1] + gc.rzx[2][k] * s0[2];
+    gk[3] = gk[4] = gk[5] = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double d3 = gc.a3[a][0] * qv[0] + gc.a3[a][1] * qv[1] + gc.a3[a][2] * qv[2];
+        const double d4 = gc.a4[a][0] * qv[0] + gc.a4[a][1] * qv[1] + gc.a4[a][2] * qv[2];
+        const double d5 = gc.a5[a][0] * s[0] + gc.a5[a][1] * s[1] + gc.a5[a][2] * s[2];
+        gk[3] += d3 * s0[a] + gc.app[0][a] * s1[a];
+        gk[4] += d4 * s0[a] + gc.app[1][a] * s1[a];
+        gk[5] += d5 * s0[a] + gc.app[2][a] * s1[a];
+    }
+    const size_t n_det = (size_t)g.ndx * g.ndz;
+    const size_t ray = (size_t)ixc * g.ndz + iz;
+    if (!FUSED) {
+        if (valid) {
+            proj[ray] = (float)val;
+            if (row_order == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) grad[k * n_det + ray] = (float)gk[k];
+            } else {
+                grad[0 * n_det + ray] = (float)gk[0]; grad[1 * n_det + ray] = (float)gk[1]; grad[2 * n_det + ray] = (float)gk[2];
+                grad[3 * n_det + ray] = (float)gk[4]; grad[4 * n_det + ray] = (float)gk[5]; grad[5 * n_det + ray] = (float)gk[3];
+            }
+        }
+    } else {
+        double part[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (valid) {
+            const float pv = (float)val;
+            const double res = (double)(bvec[(size_t)gc.b_row * n_det + ray] - pv);
+            if (resid) resid[(size_t)gc.slot * n_det + ray] = (float)res;
+            part[0] = 0.5 * res * res;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) part[1 + k] = -(double)(float)gk[k] * res;
+        }
+        __shared__ double sh[4][7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const double w = wave_sum_d(part[k]);
+            if (lane == 0) sh[wv][k] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x < 7) {
+            const int k = threadIdx.x;
+            atomicAdd(&red[(size_t)gc.slot * 7 + k], sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// projection + gradient, variant 3: four gathers per sample instead of eight.  Lanes run along detector-z, so lane l's
+// upper-z corners are normally lane l+1's lower-z corners: every lane gathers its four lower-z corners and receives the upper
+// ones from its neighbour with a DPP wave shift (v_mov_b32_dpp wave_shl:1 -- a full-rate VALU op on gfx950, tools/dpp_check.hip);
+// where the neighbour's address is not mine + 4 (tilt-induced row steps, lane 63) the lane loads them itself.  That decision
+// needs only the ADDRESSES, so the fallback loads are issued together with the main ones.
+// For the shift to read live registers the sample loop is wave-uniform over the union of the lanes' ranges; a lane outside
+// its own range still loads -- at its own ray's nearest in-range sample (always inside the padded volume), or, with no sample
+// in the block at all, at the first sample of the first lane that has one -- and its contribution is masked.  Since every
+// lane's values really are the volume at the address it advertises, "neighbour address == mine + 4" is all a lane must check.
+// The gathers are what bounds the gradient kernels under tilt (TA busy 100 %): time grows linearly with the tilt because
+// a 16-lane group then straddles more volume rows; halving the gathers halves that term.
+// ------------------------------------------------------------------------------------------------
+// lane l <- lane l + 1; lane 63 <- 0 (bound_ctrl: no `old` register to initialise)
+__device__ __forceinline__ int dpp_shl1_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
+__device__ __forceinline__ float dpp_shl1_f(float v) { return __builtin_bit_cast(float, dpp_shl1_i(__builtin_bit_cast(int, v))); }
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ pcs, const GradC *__restrict__ gcs,
+                                                      const float *__restrict__ vp, float *__restrict__ proj,
+                                                      float *__restrict__ grad, const float *__restrict__ bvec,
+                                                      float *__restrict__ resid, double *__restrict__ red, TomoGeomC g,
+                                                      int row_order)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int ix, ip, iz;
+    if (row_order & 16) {                              // cache-ordered grid, see k_proj_grad_v2
+        const int nxg = gridDim.x;
+        const int xg = ((nxg & 7) == 0) ? ((int)(blockIdx.x & 7) * (nxg >> 3) + (int)(blockIdx.x >> 3)) : (int)blockIdx.x;
+        ix = xg * 4 + wv, ip = blockIdx.y, iz = blockIdx.z * 64 + lane;
+    } else {
+        ix = blockIdx.y * 4 + wv, ip = blockIdx.z, iz = blockIdx.x * 64 + lane;
+    }
+    row_order &= 15;
+    const bool valid = (ix < g.ndx) && (iz < g.ndz);
+    const int ixc = min(ix, g.ndx - 1);
+    if (iz >= g.ndz) iz = g.ndz - 1;
+    const ProjC &c = pcs[ip];
+    const GradC &gc = gcs[ip];
+    RayCtx r;
+    ray_setup(c, g, ixc, iz, valid, r);
+    const bool nonempty = r.j1 > r.j0;
+    const int J0 = __builtin_amdgcn_readfirstlane(wave_min_i32(nonempty ? r.j0 : INT_MAX));
+    const int J1 = __builtin_amdgcn_readfirstlane(wave_max_i32(nonempty ? r.j1 : 0));
+    const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
+    const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;
+    const float sfs = (float)(g.step / c.rlen);
+    double val = 0.0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
+    for (int jb = J0; jb < J1; jb += TOMO_JB) {
+        int ia[3];
+        float f0[3];
+        tomo_block_anchor(r.b, r.d, jb, ia, f0);
+        const int64_t lin = ((int64_t)(ia[0] + TOMO_HALO) * g.nyp + (ia[1] + TOMO_HALO)) * g.nzp + (ia[2] + TOMO_HALO);
+        const int64_t lin0 = readfirstlane_i64(lin);
+        const int delta = (int)(lin - lin0);
+        const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(delta));
+        const char *sb00 = (const char *)(vp + (lin0 + m));
+        const char *sb01 = sb00 + sy4;
+        const char *sb10 = sb00 + sx4;
+        const char *sb11 = sb10 + sy4;
+        const uint32_t off0 = (uint32_t)(delta - m) * 4u;
+        const int lo = max(r.j0, jb) - jb, hi = min(r.j1, jb + TOMO_JB) - jb;      // this lane's samples of the block
+        const bool has = hi > lo;
+        const unsigned long long hm = __ballot(has);
+        if (hm == 0ull) continue;                                                  // wave-uniform
+        const int LO = __builtin_amdgcn_readfirstlane(wave_min_i32(has ? lo : INT_MAX));
+        const int HI = __builtin_amdgcn_readfirstlane(wave_max_i32(has ? hi : 0));
+        // a lane with no sample in this block gathers where the first lane that has one takes its first sample
+        uint32_t borrow;
+        {
+            const float t = (float)lo;
+            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
+            const uint32_t mine = off0 + __umul24((uint32_t)(int)floorf(x), sx4) + __umul24((uint32_t)(int)floorf(y), sy4) + ((uint32_t)(int)floorf(z) << 2);
+            borrow = (uint32_t)__builtin_amdgcn_readlane((int)mine, __builtin_ctzll(hm));
+        }
+        const int lo_c = has ? lo : 0, hi_c = has ? hi - 1 : 0;
+        const float sfb = (float)jb * sfs;
+        float av = 0.f;
+        f32x2 a0xy = {0.f, 0.f}, a1xy = {0.f, 0.f}, az = {0.f, 0.f};              // (S0x, S0y), (S1x, S1y), (S0z, S1z)
+        // issue: addresses, the four gathers, and -- decided from the addresses alone -- the fallback gathers.
+        // (Macros over plain scalars on purpose: a struct passed to helper lambdas was promoted to an LDS alloca, which put
+        // a store of every loaded value -- hence a vmcnt(0) wait -- between the two samples' loads.)
+#define GS_DECL(S) float S##v000, S##v010, S##v100, S##v110, S##f001, S##f011, S##f101, S##f111, S##wx, S##wy, S##wz, S##t; /* f*: set and read only where fb */ \
+                   bool S##act, S##fb
+#define GS_ISSUE(S, JJ)                                                                                                            \
+    {                                                                                                                              \
+        const int jc = min(max((JJ), lo_c), hi_c); /* own ray's nearest in-range sample */                                         \
+        S##act = has && jc == (JJ);                                                                                                \
+        S##t = (float)jc;                                                                                                          \
+        const float x = fmaf(S##t, dxf, f0[0]), y = fmaf(S##t, dyf, f0[1]), z = fmaf(S##t, dzf, f0[2]);                            \
+        const float fx = floorf(x), fy = floorf(y), fz = floorf(z);                                                                \
+        S##wx = x - fx; S##wy = y - fy; S##wz = z - fz;                                                                            \
+        const uint32_t vo_own = off0 + __umul24((uint32_t)(int)fx, sx4) + __umul24((uint32_t)(int)fy, sy4) + ((uint32_t)(int)fz << 2); \
+        const uint32_t vo = has ? vo_own : borrow;                                                                                 \
+        S##v000 = *(const float *)(sb00 + vo); S##v010 = *(const float *)(sb01 + vo);                                              \
+        S##v100 = *(const float *)(sb10 + vo); S##v110 = *(const float *)(sb11 + vo);                                              \
+        const uint32_t nb = (uint32_t)dpp_shl1_i((int)vo); /* lane 63 receives 0: never vo + 4 */                                 \
+        const uint32_t vo4 = vo + 4u;                                                                                              \
+        S##fb = S##act && nb != vo4;                                                                                               \
+        if (S##fb) { /* my upper-z cell is not the neighbour's lower-z cell */                                                     \
+            S##f001 = *(const float *)(sb00 + vo4); S##f011 = *(const float *)(sb01 + vo4);                                        \
+            S##f101 = *(const float *)(sb10 + vo4); S##f111 = *(const float *)(sb11 + vo4);                                        \
+        }                                                                                                                          \
+    }
+        // consume: the shifts run with every lane enabled (a DPP source lane that is masked off delivers nothing): take them
+        // first, unconditionally, then select
+#define GS_CONSUME(S)                                                                                                              \
+    {                                                                                                                              \
+        const float n001 = dpp_shl1_f(S##v000), n011 = dpp_shl1_f(S##v010), n101 = dpp_shl1_f(S##v100), n111 = dpp_shl1_f(S##v110);   \
+        const float v001 = S##fb ? S##f001 : n001, v011 = S##fb ? S##f011 : n011, v101 = S##fb ? S##f101 : n101, v111 = S##fb ? S##f111 : n111; \
+        const f32x2 p00 = {S##v000, v001}, p01 = {S##v010, v011}, p10 = {S##v100, v101}, p11 = {S##v110, v111};                    \
+        const f32x2 dy0 = p01 - p00, dy1 = p11 - p10;             /* d/dy on the x = 0 / x = 1 faces, at z and z + 1 */            \
+        const f32x2 c0 = p00 + S##wy * dy0, c1 = p10 + S##wy * dy1; /* y-lerped */                                                 \
+        const f32x2 dx = c1 - c0;                                 /* d/dx at z, z + 1 */                                           \
+        const f32x2 e = c0 + S##wx * dx;                          /* x,y-lerped value at z, z + 1 */                               \
+        const f32x2 dyx = dy0 + S##wx * (dy1 - dy0);              /* d/dy at z, z + 1 */                                           \
+        const float keep = S##act ? 1.f : 0.f;                                                                                     \
+        const float gz = keep * (e.y - e.x);                                                                                       \
+        const float gx = keep * fmaf(S##wz, dx.y - dx.x, dx.x), gy = keep * fmaf(S##wz, dyx.y - dyx.x, dyx.x);                     \
+        av = fmaf(keep, fmaf(S##wz, e.y - e.x, e.x), av);                                                                          \
+        const float sf = fmaf(S##t, sfs, sfb);                    /* (jb + jj) * step / |r0|, one rounding */                      \
+        const f32x2 gxy = {gx, gy}, one_sf = {1.f, sf};                                                                            \
+        a0xy += gxy;                                                                                                               \
+        a1xy += sf * gxy;                                                                                                          \
+        az += one_sf * gz;                                                                                                         \
+    }
+        for (int jj = LO; jj < HI; jj += 2) {                                      // wave-uniform trip count; two samples in flight
+            GS_DECL(a_);
+            GS_DECL(b_);
+            GS_ISSUE(a_, jj)
+            GS_ISSUE(b_, jj + 1)                                                   // past the end: clamped address, act = false
+            GS_CONSUME(a_)
+            GS_CONSUME(b_)
+        }
+#undef GS_DECL
+#undef GS_ISSUE
+#undef GS_CONSUME
+        val += (double)av;
+        s0[0] += (double)a0xy.x; s0[1] += (double)a0xy.y; s0[2] += (double)az.x;
+        s1[0] += (double)a1xy.x; s1[1] += (double)a1xy.y; s1[2] += (double)az.y;
+    }
+    const double s[3] = {gc.s00[0] + ixc * gc.sdx, gc.s00[1], gc.s00[2] + iz * gc.sdz};
+    double qv[3], gk[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) qv[a] = gc.ry[a][0] * s[0] + gc.ry[a][1] * s[1] + gc.ry[a][2] * s[2] + gc.t[a];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gk[k] = gc.rzx[0][k] * s0[0] + gc.rzx[1][k] * s0[1] + gc.rzx[2][k] * s0[2];
+    gk[3] = gk[4] = gk[5] = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double d3 = gc.a3[a][0] * qv[0] + gc.a3[a][1] * qv[1] + gc.a3[a][2] * qv[2];
+        const double d4 = gc.a4[a][0] * qv[0] + gc.a4[a][1] * qv[1] + gc.a4[a][2] * qv[2];
+        const double d5 = gc.a5[a][0] * s[0] + gc.a5[a][1] * s[1] + gc.a5[a][2] * s[2];
+        gk[3] += d3 * s0[a] + gc.app[0][a] * s1[a];
+        gk[4] += d4 * s0[a] + gc.app[1][a] * s1[a];
+        gk[5] += d5 * s0[a] + gc.app[2][a] * s1[a];
+    }
+    const size_t n_det = (size_t)g.ndx * g.ndz;
+    const size_t ray = (size_t)ixc * g.ndz + iz;
+    if (!FUSED) {
+        if (valid) {
+            proj[ray] = (float)val;
+            if (row_order == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) grad[k * n_det + ray] = (float)gk[k];
+            } else {
+                grad[0 * n_det + ray] = (float)gk[0]; grad[1 * n_det + ray] = (float)gk[1]; grad[2 * n_det + ray] = (float)gk[2];
+                grad[3 * n_det + ray] = (float)gk[4]; grad[4 * n_det + ray] = (float)gk[5]; grad[5 * n_det + ray] = (float)gk[3];
+            }
+        }
+    } else {
+        double part[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (valid) {
+            const float pv = (float)val;
+            const double res = (double)(bvec[(size_t)gc.b_row * n_det + ray] - pv);
+            if (resid) resid[(size_t)gc.slot * n_det + ray] = (float)res;
+            part[0] = 0.5 * res * res;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) part[1 + k] = -(double)(float)gk[k] * res;
+        }
+        __shared__ double sh[4][7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const double w = wave_sum_d(part[k]);
+            if (lane == 0) sh[wv][k] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x < 7) {
+            const int k = threadIdx.x;
+            atomicAdd(&red[(size_t)gc.slot * 7 + k], sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k]);
+        }
+    }
+}
+

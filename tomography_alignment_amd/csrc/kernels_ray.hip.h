@@ -1,0 +1,274 @@
+// kernels_ray.hip.h -- wave helpers, zero-halo staging, the ray-driven forward / adjoint kernels and the voxel-driven back-projector
+// Part of the single translation unit tomo_project.hip (included there, in this order: kernels_ray, kernels_tile,
+// kernels_grad); not compiled on its own.
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers (64 lanes)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int64_t readfirstlane_i64(int64_t v)
+{
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// ------------------------------------------------------------------------------------------------
+// zero-halo staging
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pad(const float *__restrict__ vol, float *__restrict__ vp, TomoGeomC g)
+{
+    const int row = blockIdx.x;            // ix*ny + iy
+    const int ix = row / g.ny, iy = row - ix * g.ny;
+    const float *src = vol + (size_t)row * g.nz;
+    float *dst = vp + ((size_t)(ix + TOMO_HALO) * g.nyp + (iy + TOMO_HALO)) * g.nzp + TOMO_HALO;
+    for (int z = threadIdx.x; z < g.nz; z += blockDim.x) dst[z] = src[z];
+}
+
+__global__ __launch_bounds__(256) void k_unpad(float *__restrict__ vol, const float *__restrict__ vp, TomoGeomC g, int accumulate)
+{
+    const int row = blockIdx.x;
+    const int ix = row / g.ny, iy = row - ix * g.ny;
+    float *dst = vol + (size_t)row * g.nz;
+    const float *src = vp + ((size_t)(ix + TOMO_HALO) * g.nyp + (iy + TOMO_HALO)) * g.nzp + TOMO_HALO;
+    if (accumulate)
+        for (int z = threadIdx.x; z < g.nz; z += blockDim.x) dst[z] += src[z];
+    else
+        for (int z = threadIdx.x; z < g.nz; z += blockDim.x) dst[z] = src[z];
+}
+
+static int stage_volume(tomo_ctx *ctx, const float *d_vol)
+{
+    const TomoGeomC &g = ctx->g;
+    if (ctx->reuse_staged && !ctx->halo_dirty && ctx->staged_src == (const void *)d_vol) return TOMO_OK;   // caller vouches: unchanged
+    ctx->staged_src = (const void *)d_vol;
+    if (ctx->halo_dirty) {
+        TOMO_HIP(ctx, hipMemsetAsync(ctx->d_volpad, 0, ctx->volpad_elems * sizeof(float), ctx->stream));
+        ctx->halo_dirty = false;
+    }
+    TOMO_LAUNCH(ctx, "k_pad", k_pad, dim3(g.nx * g.ny), dim3(256), 0, d_vol, ctx->d_volpad, g);
+    return TOMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-ray set-up shared by the ray-driven kernels
+// ------------------------------------------------------------------------------------------------
+struct RayCtx {
+    double b[3], d[3];
+    int j0, j1;
+};
+
+__device__ __forceinline__ void ray_setup(const ProjC &c, const TomoGeomC &g, int ix, int iz, bool valid, RayCtx &r)
+{
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        r.b[a] = c.p0[a] + (double)ix * c.u[a] + (double)iz * c.w[a];
+        r.d[a] = c.d[a];
+    }
+    tomo_ray_range(r.b, r.d, c.n, g.nx, g.ny, g.nz, r.j0, r.j1);
+    if (!valid) r.j0 = r.j1 = 0;
+}
+
+// trilinear value from the 8 loaded corners: v000 + wz*(v001-v000) ... == sum rec*wx*wy*wz of
+// src/ray_wt_grad.f90:143-145 with wf = 1-wc (utilities/ray_voxel_utilities.py:98-99)
+__device__ __forceinline__ float trilerp(float v000, float v001, float v010, float v011, float v100, float v101, float v110,
+                                         float v111, float wx, float wy, float wz)
+{
+    float c00 = fmaf(wz, v001 - v000, v000);
+    float c01 = fmaf(wz, v011 - v010, v010);
+    float c10 = fmaf(wz, v101 - v100, v100);
+    float c11 = fmaf(wz, v111 - v110, v110);
+    float e0 = fmaf(wy, c01 - c00, c00);
+    float e1 = fmaf(wy, c11 - c10, c10);
+    return fmaf(wx, e1 - e0, e0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward projection, variant 1: plain 64-bit indexing (reference form of the algorithm)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwd_v1(const ProjC *__restrict__ pcs, const float *__restrict__ vp,
+                                                float *__restrict__ proj, TomoGeomC g)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int iz = blockIdx.x * 64 + lane, ix = blockIdx.y * 4 + wv, ip = blockIdx.z;
+    if (ix >= g.ndx || iz >= g.ndz) return;
+    const ProjC &c = pcs[ip];
+    RayCtx r;
+    ray_setup(c, g, ix, iz, true, r);
+    const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
+    const int64_t sy = g.nzp, sx = (int64_t)g.nyp * g.nzp;
+    double total = 0.0;
+    for (int jb = r.j0; jb < r.j1; jb += TOMO_JB) {
+        int ia[3];
+        float f0[3];
+        tomo_block_anchor(r.b, r.d, jb, ia, f0);
+        const float *base = vp + ((int64_t)(ia[0] + TOMO_HALO) * sx + (int64_t)(ia[1] + TOMO_HALO) * sy + (ia[2] + TOMO_HALO));
+        const int cnt = min(TOMO_JB, r.j1 - jb);
+        float acc = 0.f;
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float t = (float)jj;
+            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
+            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+            const float *q = base + ((int64_t)(int)fx * sx + (int64_t)(int)fy * sy + (int)fz);
+            acc += trilerp(q[0], q[1], q[sy], q[sy + 1], q[sx], q[sx + 1], q[sx + sy], q[sx + sy + 1], x - fx, y - fy, z - fz);
+        }
+        total += (double)acc;
+    }
+    proj[((size_t)ip * g.ndx + ix) * g.ndz + iz] = (float)total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward projection, variant 2: wave-uniform 64-bit block base in SGPRs + one unsigned 32-bit byte
+// offset per lane shared by all 8 corner loads (global_load_dword v, v_off, s[base], offset:0|4).
+// The block loop runs over the wave-uniform union of the lanes' sample ranges so the cross-lane
+// minimum is taken with every lane active.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwd_v2(const ProjC *__restrict__ pcs, const float *__restrict__ vp,
+                                                float *__restrict__ proj, TomoGeomC g)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ix = blockIdx.y * 4 + wv, ip = blockIdx.z;
+    if (ix >= g.ndx) return;                       // wave-uniform exit
+    int iz = blockIdx.x * 64 + lane;
+    const bool valid = iz < g.ndz;
+    if (!valid) iz = g.ndz - 1;                    // keep the lane's arithmetic in range; it contributes nothing
+    const ProjC &c = pcs[ip];
+    RayCtx r;
+    ray_setup(c, g, ix, iz, valid, r);
+    const bool nonempty = r.j1 > r.j0;
+    const int J0 = __builtin_amdgcn_readfirstlane(wave_min_i32(nonempty ? r.j0 : INT_MAX));
+    const int J1 = __builtin_amdgcn_readfirstlane(wave_max_i32(nonempty ? r.j1 : 0));
+    const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
+    const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;
+    // dword gathers on purpose (a wave-wide dwordx2 costs 3.5x a dword in the L1 pipeline, tools/gather_bench.hip): the z + 1
+    // bases carry an offset the compiler cannot see through, so it does not fuse the corner pairs
+    int four;
+    asm volatile("s_mov_b32 %0, 4" : "=s"(four));
+    double total = 0.0;
+    for (int jb = J0; jb < J1; jb += TOMO_JB) {
+        int ia[3];
+        float f0[3];
+        tomo_block_anchor(r.b, r.d, jb, ia, f0);
+        const int64_t lin = ((int64_t)(ia[0] + TOMO_HALO) * g.nyp + (ia[1] + TOMO_HALO)) * g.nzp + (ia[2] + TOMO_HALO);
+        const int64_t lin0 = readfirstlane_i64(lin);
+        const int delta = (int)(lin - lin0);       // neighbouring rays at the same j: a few rows apart
+        const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(delta));
+        const char *sb00 = (const char *)(vp + (lin0 + m));
+        const char *sb01 = sb00 + sy4;
+        const char *sb10 = sb00 + sx4;
+        const char *sb11 = sb10 + sy4;
+        const char *sc00 = sb00 + four, *sc01 = sb01 + four, *sc10 = sb10 + four, *sc11 = sb11 + four;
+        const uint32_t off0 = (uint32_t)(delta - m) * 4u;
+        const int lo = max(r.j0, jb) - jb, hi = min(r.j1, jb + TOMO_JB) - jb;
+        float acc = 0.f;
+        for (int jj = lo; jj < hi; ++jj) {
+            const float t = (float)jj;
+            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
+            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+            const uint32_t vo = off0 + __umul24((uint32_t)(int)fx, sx4) + __umul24((uint32_t)(int)fy, sy4) + ((uint32_t)(int)fz << 2);
+            const float v000 = *(const float *)(sb00 + vo), v001 = *(const float *)(sc00 + vo);
+            const float v010 = *(const float *)(sb01 + vo), v011 = *(const float *)(sc01 + vo);
+            const float v100 = *(const float *)(sb10 + vo), v101 = *(const float *)(sc10 + vo);
+            const float v110 = *(const float *)(sb11 + vo), v111 = *(const float *)(sc11 + vo);
+            acc += trilerp(v000, v001, v010, v011, v100, v101, v110, v111, x - fx, y - fy, z - fz);
+        }
+        total += (double)acc;
+    }
+    if (valid) proj[((size_t)ip * g.ndx + ix) * g.ndz + iz] = (float)total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// adjoint, variant 1: the same traversal scattering w*y with global float atomics into the padded
+// scratch volume (halo swallows the out-of-bounds corners).  Atomic-rate bound (~1.3 TB/s of added
+// bytes, MI355X_MICROARCH 'Global float atomics'): kept as the simple reference form for parity.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adj_v1(const ProjC *__restrict__ pcs, const float *__restrict__ proj,
+                                                float *__restrict__ vp, TomoGeomC g)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int iz = blockIdx.x * 64 + lane, ix = blockIdx.y * 4 + wv, ip = blockIdx.z;
+    if (ix >= g.ndx || iz >= g.ndz) return;
+    const ProjC &c = pcs[ip];
+    RayCtx r;
+    ray_setup(c, g, ix, iz, true, r);
+    const float yv = proj[((size_t)ip * g.ndx + ix) * g.ndz + iz];
+    const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
+    const int64_t sy = g.nzp, sx = (int64_t)g.nyp * g.nzp;
+    for (int jb = r.j0; jb < r.j1; jb += TOMO_JB) {
+        int ia[3];
+        float f0[3];
+        tomo_block_anchor(r.b, r.d, jb, ia, f0);
+        float *base = vp + ((int64_t)(ia[0] + TOMO_HALO) * sx + (int64_t)(ia[1] + TOMO_HALO) * sy + (ia[2] + TOMO_HALO));
+        const int cnt = min(TOMO_JB, r.j1 - jb);
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float t = (float)jj;
+            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
+            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+            const float wcx = x - fx, wcy = y - fy, wcz = z - fz;
+            const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
+            float *q = base + ((int64_t)(int)fx * sx + (int64_t)(int)fy * sy + (int)fz);
+            const float a0 = yv * wfx, a1 = yv * wcx;
+            const float b00 = a0 * wfy, b01 = a0 * wcy, b10 = a1 * wfy, b11 = a1 * wcy;
+            atomicAdd(q, b00 * wfz);
+            atomicAdd(q + 1, b00 * wcz);
+            atomicAdd(q + sy, b01 * wfz);
+            atomicAdd(q + sy + 1, b01 * wcz);
+            atomicAdd(q + sx, b10 * wfz);
+            atomicAdd(q + sx + 1, b10 * wcz);
+            atomicAdd(q + sx + sy, b11 * wfz);
+            atomicAdd(q + sx + sy + 1, b11 * wcz);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// voxel-driven bilinear back-projector (src/back_projection.f90:25-32): one voxel per work-item,
+// lanes along z, loop over projections with the accumulator in a register; the voxel centre is
+// transformed on the fly (the reference re-reads a (3,n_vox) voxel_centers array per projection).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bp_voxel(const BpC *__restrict__ cs, int n_proj, const float *__restrict__ det,
+                                                  float *__restrict__ vol, TomoGeomC g)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int iz = blockIdx.x * 64 + lane, iy = blockIdx.y * 4 + wv, ix = blockIdx.z;
+    if (iy >= g.ny || iz >= g.nz) return;
+    const size_t img = (size_t)g.ndx * g.ndz;
+    float acc = 0.f;
+    for (int ip = 0; ip < n_proj; ++ip) {
+        const BpC c = cs[ip];
+        const double u = c.u0 + ix * c.ux + iy * c.uy + iz * c.uz;
+        const double v = c.v0 + ix * c.vx + iy * c.vy + iz * c.vz;
+        if (!(u >= -1.0 && u < (double)g.ndx && v >= -1.0 && v < (double)g.ndz)) continue;
+        const double fu = floor(u), fv = floor(v);
+        const int fx = (int)fu, fz = (int)fv;
+        const float ax = (float)(u - fu), az = (float)(v - fv);      // external_back_projection.f90:47-48
+        const float *im = det + (size_t)ip * img;
+        const bool x0 = fx >= 0, x1 = fx + 1 < g.ndx, z0 = fz >= 0, z1 = fz + 1 < g.ndz;
+        float s = 0.f;                                                 // :54-65, per-pixel bounds tests
+        if (x0 && z0) s += im[(size_t)fx * g.ndz + fz] * (1.f - ax) * (1.f - az);
+        if (x1 && z0) s += im[(size_t)(fx + 1) * g.ndz + fz] * ax * (1.f - az);
+        if (x0 && z1) s += im[(size_t)fx * g.ndz + fz + 1] * (1.f - ax) * az;
+        if (x1 && z1) s += im[(size_t)(fx + 1) * g.ndz + fz + 1] * ax * az;
+        acc += s;                                                      // back_projection.f90:31
+    }
+    vol[((size_t)ix * g.ny + iy) * g.nz + iz] = acc;
+}
+
