@@ -310,11 +310,17 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
         // the voxel x range the tile columns [xt0, xt1) finalise (the tile grid starts at x = -1)
         const int xs = std::max(0, ATX * xt0 - 1), xe = (xt1 == n_xt) ? g.nx : std::min(g.nx, ATX * xt1 - 1);
         if (xe > xs) {
-            const dim3 ggrid((g.nz + 64 * GWAVES - 1) / (64 * GWAVES), (g.ny + GTY - 1) / GTY, (xe - xs + GTX - 1) / GTX);
+            // one-dimensional grid of patches (see the kernel): ceil(#patches / 8) groups of 8 patches x GPX*GPY tiles
+            const int ntx = (xe - xs + GTX - 1) / GTX, nty = (g.ny + GTY - 1) / GTY, nzq = (g.nz + 64 * GWAVES - 1) / (64 * GWAVES);
+            const long long n_patch = (long long)nzq * ((ntx + GPX - 1) / GPX) * ((nty + GPY - 1) / GPY);
+            const int patched = n_patch >= 256 ? 1 : 0;
+            const long long n_wg = patched ? ((n_patch + 7) / 8) * 8 * (GPX * GPY) : (long long)nzq * ntx * nty;
+            if (n_wg >= ((long long)1 << 31)) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "gather adjoint: grid too large");
+            const dim3 ggrid((unsigned)n_wg);
             if (ctx->tile_cache_eb_max < 1.49)
-                TOMO_LAUNCH(ctx, "k_adj_gather_flat", k_adj_gather_flat<3>, ggrid, dim3(GWAVES * 64), 0, d_gfc, n_gather, d_proj, d_vol, g, xs, xe);
+                TOMO_LAUNCH(ctx, "k_adj_gather_flat", k_adj_gather_flat<3>, ggrid, dim3(GWAVES * 64), 0, d_gfc, n_gather, d_proj, d_vol, g, xs, xe, patched);
             else        // finer sampling along the rays (step down to ~0.475 voxel): six samples per row can reach a column
-                TOMO_LAUNCH(ctx, "k_adj_gather_flat", k_adj_gather_flat<6>, ggrid, dim3(GWAVES * 64), 0, d_gfc, n_gather, d_proj, d_vol, g, xs, xe);
+                TOMO_LAUNCH(ctx, "k_adj_gather_flat", k_adj_gather_flat<6>, ggrid, dim3(GWAVES * 64), 0, d_gfc, n_gather, d_proj, d_vol, g, xs, xe, patched);
         }
     }
     if (n_proj == n_gather) return TOMO_OK;
