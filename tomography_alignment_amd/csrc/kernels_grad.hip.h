@@ -376,8 +376,7 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
         }
         const int lo_c = has ? lo : 0, hi_c = has ? hi - 1 : 0;
         const float sfb = (float)jb * sfs;
-        float av = 0.f;
-        f32x2 a0xy = {0.f, 0.f}, a1xy = {0.f, 0.f}, az = {0.f, 0.f};              // (S0x, S0y), (S1x, S1y), (S0z, S1z)
+        float av = 0.f, a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
         // issue: addresses, the four gathers, and -- decided from the addresses alone -- the fallback gathers.
         // (Macros over plain scalars on purpose: a struct passed to helper lambdas was promoted to an LDS alloca, which put
         // a store of every loaded value -- hence a vmcnt(0) wait -- between the two samples' loads.)
@@ -409,21 +408,23 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
     {                                                                                                                              \
         const float n001 = dpp_shl1_f(S##v000), n011 = dpp_shl1_f(S##v010), n101 = dpp_shl1_f(S##v100), n111 = dpp_shl1_f(S##v110);   \
         const float v001 = S##fb ? S##f001 : n001, v011 = S##fb ? S##f011 : n011, v101 = S##fb ? S##f101 : n101, v111 = S##fb ? S##f111 : n111; \
-        const f32x2 p00 = {S##v000, v001}, p01 = {S##v010, v011}, p10 = {S##v100, v101}, p11 = {S##v110, v111};                    \
-        const f32x2 dy0 = p01 - p00, dy1 = p11 - p10;             /* d/dy on the x = 0 / x = 1 faces, at z and z + 1 */            \
-        const f32x2 c0 = p00 + S##wy * dy0, c1 = p10 + S##wy * dy1; /* y-lerped */                                                 \
-        const f32x2 dx = c1 - c0;                                 /* d/dx at z, z + 1 */                                           \
-        const f32x2 e = c0 + S##wx * dx;                          /* x,y-lerped value at z, z + 1 */                               \
-        const f32x2 dyx = dy0 + S##wx * (dy1 - dy0);              /* d/dy at z, z + 1 */                                           \
+        /* scalar lerps on purpose: with the corners arriving one register at a time (loads, shifts, selects), packed ops     */ \
+        /* needed ~11 v_mov per sample just to pair their operands -- a fifth of this VALU-bound kernel's instructions      */ \
+        const float d00 = v001 - S##v000, d01 = v011 - S##v010, d10 = v101 - S##v100, d11 = v111 - S##v110; /* d/dz */             \
+        const float c00 = fmaf(S##wz, d00, S##v000), c01 = fmaf(S##wz, d01, S##v010);                                              \
+        const float c10 = fmaf(S##wz, d10, S##v100), c11 = fmaf(S##wz, d11, S##v110);            /* z-lerped corners */            \
+        const float dz0 = fmaf(S##wy, d01 - d00, d00), dz1 = fmaf(S##wy, d11 - d10, d10);                                          \
+        const float dy0 = c01 - c00, dy1 = c11 - c10;                                                                              \
+        const float e0 = fmaf(S##wy, dy0, c00), e1 = fmaf(S##wy, dy1, c10);                                                        \
         const float keep = S##act ? 1.f : 0.f;                                                                                     \
-        const float gz = keep * (e.y - e.x);                                                                                       \
-        const float gx = keep * fmaf(S##wz, dx.y - dx.x, dx.x), gy = keep * fmaf(S##wz, dyx.y - dyx.x, dyx.x);                     \
-        av = fmaf(keep, fmaf(S##wz, e.y - e.x, e.x), av);                                                                          \
+        const float gz = keep * fmaf(S##wx, dz1 - dz0, dz0);                                                                       \
+        const float gy = keep * fmaf(S##wx, dy1 - dy0, dy0);                                                                       \
+        const float gx0 = e1 - e0;                                                                                                 \
+        const float gx = keep * gx0;                                                                                               \
+        av = fmaf(keep, fmaf(S##wx, gx0, e0), av);                                                                                 \
         const float sf = fmaf(S##t, sfs, sfb);                    /* (jb + jj) * step / |r0|, one rounding */                      \
-        const f32x2 gxy = {gx, gy}, one_sf = {1.f, sf};                                                                            \
-        a0xy += gxy;                                                                                                               \
-        a1xy += sf * gxy;                                                                                                          \
-        az += one_sf * gz;                                                                                                         \
+        a0x += gx; a0y += gy; a0z += gz;                                                                                           \
+        a1x = fmaf(sf, gx, a1x); a1y = fmaf(sf, gy, a1y); a1z = fmaf(sf, gz, a1z);                                                 \
     }
         for (int jj = LO; jj < HI; jj += 2) {                                      // wave-uniform trip count; two samples in flight
             GS_DECL(a_);
@@ -437,8 +438,8 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
 #undef GS_ISSUE
 #undef GS_CONSUME
         val += (double)av;
-        s0[0] += (double)a0xy.x; s0[1] += (double)a0xy.y; s0[2] += (double)az.x;
-        s1[0] += (double)a1xy.x; s1[1] += (double)a1xy.y; s1[2] += (double)az.y;
+        s0[0] += (double)a0x; s0[1] += (double)a0y; s0[2] += (double)a0z;
+        s1[0] += (double)a1x; s1[1] += (double)a1y; s1[2] += (double)a1z;
     }
     const double s[3] = {gc.s00[0] + ixc * gc.sdx, gc.s00[1], gc.s00[2] + iz * gc.sdz};
     double qv[3], gk[6];
