@@ -276,6 +276,23 @@ def projection_gradient(geo, rec, alpha, beta, phi, xyz_shift, cor_shift3, preci
     return img.astype(precision, copy=False), grad.astype(precision, copy=False)
 
 
+def ray_face_distance(geo, alpha, beta, phi, xyz_shift, cor_shift3):
+    """Test aid: per ray, the smallest distance (voxels) of an in-volume sample to a cell face (orc_ray_face_distance).
+    The pose gradient of a ray with a sample within position rounding of a face is ill-conditioned (the interpolant's
+    spatial gradient jumps there, its value does not)."""
+    p0, rhat, n, r_len0, src, det = ray_setup(geo, alpha, beta, phi, xyz_shift, cor_shift3)
+    nx, ny, nz = (int(v) for v in geo.vox_shape)
+    out = np.ones(geo.n_det, np.float64)
+    _lib().orc_ray_face_distance(_p(p0), _p(rhat), ctypes.c_int64(geo.n_det), n, ctypes.c_double(geo.step_size),
+                                 nx, ny, nz, _p(out))
+    return out
+
+
+def set_threads(n):
+    """OpenMP threads of the ray loops (forward, adjoint, projection_gradient); 1 = the serial reference's shape."""
+    _lib().orc_set_threads(int(n))
+
+
 # ----------------------------------------------------------------------------------------
 # A6: voxel-driven back_project (src/back_projection.f90:1-34), float32
 # ----------------------------------------------------------------------------------------

@@ -412,6 +412,61 @@ def test_gradient_kernel_variants_agree_on_odd_shapes(PM, orc, shape, ndet):
         assert rel_max(out[3][0], out[2][0]) < 1e-6 and rel_max(out[3][1], out[2][1]) < 1e-6    # same arithmetic, other data path
 
 
+@pytest.mark.parametrize("case", ["lane63_only", "lane0_only", "short_row", "all_miss", "lane63_only_tilted", "one_row_tilted"])
+def test_gradient_kernels_idle_lane_addressing(PM, orc, case):
+    """Regression for the GPU abort of round 1: the first neighbour-lane-shift gradient kernel let lanes
+    OUTSIDE their own sample range [lo, hi) form gather addresses from their out-of-volume positions -- a wave-uniform sample
+    loop with every lane loading -- and faulted as soon as such an address left mapped memory.  Today every lane loads either at
+    a sample of its own range or at the borrowed address of a lane that has one.  The shapes here make that path the common
+    one: a wave whose only in-range lane is lane 63 at iz = ndz - 1 (or lane 0), rows of rays that all miss the volume,
+    a detector row shorter than a wave, and a launch in which no ray hits at all -- for every kernel variant, plain and fused."""
+    from tomography_alignment_amd import _lib
+    shape, ndet, phi, alpha, beta = (8, 8, 8), (40, 64), 0.4, 0.0, 0.0
+    t = np.array([0.3, 0.2, -35.5])                   # only iz = 63 floors into the volume (index z = -0.5)
+    if case == "lane0_only":
+        t = np.array([0.3, 0.2, 35.5])                # only iz = 0 (index z = 7.5)
+    elif case == "short_row":
+        shape, ndet, t = (8, 8, 5), (12, 5), np.array([0.4, 0.0, 0.3])
+    elif case == "all_miss":
+        t = np.array([100.0, 0.0, 0.0])
+    elif case == "lane63_only_tilted":
+        alpha, beta, t = np.deg2rad(3.0), np.deg2rad(-2.0), np.array([0.3, 0.2, -35.2])
+    elif case == "one_row_tilted":
+        shape, ndet, alpha, beta, t = (6, 6, 70), (30, 130), np.deg2rad(-4.0), np.deg2rad(5.0), np.array([-9.5, 0.0, 2.0])
+    rng = np.random.default_rng(63)
+    geo, og = geo_pair(1, None, ndet=ndet, shape=shape)
+    x = rng.uniform(0.1, 1, shape).astype(np.float32)
+    cor = np.array([0.25, 0., 0.])
+    want_p, want_g = orc.projection_gradient(og, x, alpha, beta, phi, t, cor, precision=np.float64)
+    hit = int(np.count_nonzero(want_p))
+    assert (hit == 0) == (case == "all_miss")
+    if case in ("lane63_only", "lane0_only"):
+        only = 63 if case == "lane63_only" else 0
+        assert set(np.nonzero(want_p.reshape(ndet))[1]) == {only}
+    n_det = ndet[0] * ndet[1]
+    pose = _lib.poses_array([phi], [alpha], [beta], t, cor)
+    b = (want_p + 0.1).astype(np.float32)
+    res = b.astype(np.float64) - want_p.astype(np.float32)
+    for v in (1, 2, 3, 4):
+        P = PM(geo, precision=np.float64)
+        be = P.backend
+        be.ctx.set_option("grad_variant", v)
+        p, g = P.projection_gradient(x, alpha, beta, phi, t, cor)
+        if hit:
+            assert rel_max(p, want_p) < TOL, (case, v)
+            for k in range(6):
+                assert rel_max(g[k], want_g[k]) < TOL, (case, v, k)
+        else:
+            assert not p.any() and not g.any(), (case, v)
+        two = np.ascontiguousarray(np.repeat(pose, 2, axis=0))
+        two[1, 5] += 200.0                                # second pose of the fused launch misses the volume entirely
+        cost, g6 = be.cost_grad(two, be.upload(x), be.upload(np.concatenate([b, b])))
+        assert np.isclose(cost[0], 0.5 * np.dot(res, res), rtol=1e-6) and np.isclose(cost[1], 0.5 * np.dot(b.astype(np.float64), b), rtol=1e-6)
+        want6 = -np.dot(want_g.astype(np.float32).astype(np.float64), res)
+        assert np.max(np.abs(g6[0] - want6)) <= TOL * max(np.dot(np.abs(want_g), np.abs(res)).max(), 1e-30), (case, v)
+        assert not g6[1].any()
+
+
 @pytest.mark.parametrize("ndet", [(384, 340), (402, 350)])      # 96 ix groups (XCD swizzle) / 101 (plain)
 def test_cost_grad_cache_ordered_grid_vs_oracle(PM, orc, ndet):
     """Volumes whose padded copy exceeds the Infinity Cache make grad_variant 2 walk the grid detector-z-chunk slowest

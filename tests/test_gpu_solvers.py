@@ -202,24 +202,35 @@ def test_pipelined_allreduce_path_matches_plain(shepp32):
     comm.close()
 
 
-def test_staged_volume_reuse_is_safe(shepp32):
-    """Alignment loops evaluate many poses against one pinned volume: the zero-padded staging copy is reused, and a changed
-    volume (new host contents, or a device buffer after invalidate_volume()) is picked up."""
+def test_volume_residency_is_explicit(shepp32):
+    """Like the reference, projection_gradient re-reads `rec` on every call; a volume stays resident (upload and zero-padded
+    staging skipped) only while the caller has pinned it."""
     from tomography_alignment_amd.utilities import projection_operators
-    geo = geom(1, 32)
+    from tomography_alignment_amd.utilities.generate_phantom import shepp3d
+    N = 128
+    geo = geom(1, N)
     P = projection_operators.ProjectionMatrix(geo)
     pose = dict(alpha=0.01, beta=-0.02, phi=0.8, xyz_shift=np.array([0.5, 0., -0.7]), cor_shift=np.zeros(3))
-    x = shepp32.copy()
+    x = shepp3d(N)                                      # z = 0 plane and corner voxels empty (ADVICE r1: strided fingerprints miss edits)
+    assert not x[:, :, 0].any() and x.ravel()[-1] == 0
     p1, g1 = P.projection_gradient(x, **pose)
-    p2, _ = P.projection_gradient(x, **pose)            # staged copy reused
-    assert np.array_equal(p1, p2) and P._vol_staged
-    x2 = 2.0 * x
-    p3, g3 = P.projection_gradient(x2, **pose)          # new host contents: re-uploaded and re-staged
-    assert rel_max(p3, 2.0 * p1) < 1e-6 and rel_max(g3, 2.0 * g1) < 1e-6
+    assert not P._vol_staged
+    x *= 2.0                                            # in-place edit of an unpinned host volume: must be seen
+    p2, g2 = P.projection_gradient(x, **pose)
+    assert rel_max(p2, 2.0 * p1) < 1e-6 and rel_max(g2, 2.0 * g1) < 1e-6
+    x[x < 0.5] = 0.0
+    x *= 0.5
+    P.pin_volume(x)
+    p3, _ = P.projection_gradient(x, **pose)
+    p4, _ = P.projection_gradient(x, **pose)            # pinned: staged copy reused
+    assert np.array_equal(p3, p4) and P._vol_staged
+    x *= 3.0                                            # the caller breaks the promise ...
+    P.invalidate_volume()                               # ... and says so
+    p5, _ = P.projection_gradient(x, **pose)
+    assert rel_max(p5, 3.0 * p3) < 1e-6
+    P.unpin_volume()
     d = P.backend.upload(x)
-    p4, _ = P.projection_gradient(d, **pose)
-    assert rel_max(p4, p1) < 1e-7
-    d.upload(3.0 * x)                                   # mutated in place behind the operator's back ...
-    P.invalidate_volume()                               # ... so the caller says so
-    p5, _ = P.projection_gradient(d, **pose)
-    assert rel_max(p5, 3.0 * p1) < 1e-6
+    p6, _ = P.projection_gradient(d, **pose)            # device buffer, unpinned: re-staged on every call
+    d.upload(2.0 * x)                                   # mutated in place behind the operator's back
+    p7, _ = P.projection_gradient(d, **pose)
+    assert rel_max(p6, p5) < 1e-7 and rel_max(p7, 2.0 * p5) < 1e-6

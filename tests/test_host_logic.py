@@ -54,6 +54,30 @@ def test_no_gpu_means_loud_failure(built_lib):
         projection_operators.ProjectionMatrix(geom(2, 8)).projection_matrix()   # no silent CPU fallback
 
 
+def test_geometry_check_guards_without_a_gpu(built_lib):
+    """tomo_check_geometry (the validation inside tomo_set_geometry) runs on the host: bad shapes, the 2^31-voxel limit, and
+    the wide-row flag that keeps the 24-bit-multiply kernels away from slabs whose x-row pitch is >= 2^24 bytes."""
+    def check(shape, ndet=(8, 8), step=1.0):
+        g = _lib.TomoGeom()
+        g.nx, g.ny, g.nz = shape
+        g.ndx, g.ndz = ndet
+        g.src_y, g.det_y, g.step = -10.0, 10.0, step
+        g.det_dx = g.det_dz = 1.0
+        flags = ctypes.c_int(-1)
+        return built_lib.tomo_check_geometry(ctypes.byref(g), ctypes.byref(flags)), flags.value
+    assert check((64, 64, 64)) == (0, 0)
+    assert check((1024, 1024, 1024)) == (0, 0)                 # row pitch 1028 * 1028 * 4 = 4.2 MB < 2^24
+    assert check((16, 2044, 2048)) == (0, _lib.GEOM_WIDE_ROWS)  # 2048 * 2052 * 4 = 16 809 984 >= 2^24 = 16 777 216
+    rc, fl = check((16, 2045, 2045))                           # 2049 * 2049 * 4 = 16 793 604 >= 2^24 = 16 777 216
+    assert rc == 0 and fl == _lib.GEOM_WIDE_ROWS
+    rc, fl = check((16, 4096, 4096))
+    assert rc == 0 and fl == _lib.GEOM_WIDE_ROWS
+    assert check((16, 2040, 2040)) == (0, 0)                   # 2044 * 2044 * 4 = 16 711 744 < 2^24
+    assert check((2048, 2048, 2048))[0] == -5                  # TOMO_ERR_UNSUPPORTED: padded volume >= 2^31 voxels
+    assert check((0, 8, 8))[0] == -2 and check((8, 8, 8), step=0.0)[0] == -2
+    assert check((2048, 2048, 2048))[0] == -5 and b"2^31" in built_lib.tomo_last_error(None)
+
+
 def test_geometry_conventions():
     g = geom(3, 8)
     assert np.allclose(g.vox_origin, [-3.5, -3.5, -3.5])                 # geometry.py:82-87
@@ -184,15 +208,46 @@ def test_alignment_cost_gradient_pairs_vs_reference_golden(shepp32):
     assert rel_max(fd, g["grad_xz"]) < 5e-2
 
 
-def test_fused_evaluation_is_memoised(shepp32):
+def test_fused_evaluation_is_memoised_only_while_pinned(shepp32):
     g, P, ao, args = _alignment_setup(shepp32)
     be = P.backend
     p = g["p_gen"]
+    # unpinned: the volume is re-read on every call, like the reference (utilities/projection_operators.py:112-122)
     alignment_functions.cost_xzab(p, *args)
     alignment_functions.gradient_xzab(p, *args)
-    assert be.calls["cost_grad"] == 1          # fun(x) then jac(x): one fused launch
-    alignment_functions.gradient_xzab(p + 1e-3, *args)
     assert be.calls["cost_grad"] == 2
+    # pinned ("I will not modify rec"): fun(x) then jac(x) = one fused launch
+    P.pin_volume(args[1])
+    c0 = alignment_functions.cost_xzab(p, *args)
+    alignment_functions.gradient_xzab(p, *args)
+    assert be.calls["cost_grad"] == 3
+    alignment_functions.gradient_xzab(p + 1e-3, *args)
+    assert be.calls["cost_grad"] == 4
+    P.invalidate_volume()                      # "I did modify it": evaluated afresh, still pinned afterwards
+    alignment_functions.cost_xzab(p + 1e-3, *args)
+    assert be.calls["cost_grad"] == 5 and P.volume_is_pinned(args[1])
+    P.unpin_volume()
+    assert np.isclose(alignment_functions.cost_xzab(p, *args), c0, rtol=1e-12) and be.calls["cost_grad"] == 6
+
+
+def test_in_place_edit_of_an_unpinned_volume_is_seen():
+    """a phantom whose z = 0 plane and last voxel are empty, edited in place -- a fingerprint of strided
+    samples cannot see the edit; every call must use the current contents."""
+    N = 16
+    geo = geom(1, N)
+    P = projection_operators.ProjectionMatrix(geo, backend=OracleBackend(geo))
+    rec = np.zeros((N, N, N), np.float32)
+    rec[4:12, 4:12, 4:12] = 1.0
+    pose = dict(alpha=0.01, beta=-0.02, phi=0.8, xyz_shift=np.array([0.5, 0., -0.7]), cor_shift=np.zeros(3))
+    p1, g1 = P.projection_gradient(rec, **pose)
+    rec *= 3.0                                  # in place: same pointer, shape, dtype; z = 0 plane and last voxel still 0
+    p2, g2 = P.projection_gradient(rec, **pose)
+    assert rel_max(p2, 3.0 * p1) < 1e-6 and rel_max(g2, 3.0 * g1) < 1e-6
+    ao = alignment_functions.AlignmentUtilities(p1.reshape(N, N), P, type("G", (), {"cor_shift": np.zeros(3)})())
+    c3 = ao.cost_and_gradient(rec, (0.8, 0.01, -0.02), pose["xyz_shift"])[0]
+    rec[rec > 0] = 1.0                          # back to the original, in place
+    c1 = ao.cost_and_gradient(rec, (0.8, 0.01, -0.02), pose["xyz_shift"])[0]
+    assert c3 > 1.0 and c1 < 1e-8 * c3
 
 
 def test_lbfgs_pose_recovery_and_gradient_descent_vs_reference_golden(shepp32):

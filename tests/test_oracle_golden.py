@@ -136,3 +136,31 @@ def test_g8_voxel_splat():
         img, grad = orc.vox_forward_proj_grad(G, g["alpha"][i], g["beta"][i], g["phi"][i], g["xyz"][i], g["cor"][i], x)
         assert rel_max(img, g["img%d" % i]) < 2e-6
         assert rel_max(grad, g["grad%d" % i]) < 2e-5
+
+
+def test_sirt_sensitivity_to_operator_rounding():
+    """How far does the reference's own SIRT iterate move when its operators are perturbed at float32-rounding size?  This
+    conditioning number is what the 10-iteration GPU parity bounds are derived from (tests/test_gpu_solvers.py,
+    tests/test_gpu_configs.py): forward / adjoint outputs get i.i.d. noise of eps * max|output| (eps = 1e-6: the measured
+    size of the HIP kernels' rel-max deviation from the oracle per application), G5 inputs, 10 iterations."""
+    g = golden("g5_sirt")
+    gt = golden("g7_phantom")["shepp32"]
+    og = orc.Geo(16, np.array([32] * 3), np.ones(3), np.array([32, 32]), np.ones(2))
+    kw = dict(alpha=g["alpha"], beta=g["beta"], phi=g["phi"], xyz_shift=g["xyz"])
+    fwd = lambda x: orc.forward(og, x, **kw).astype(np.float32).ravel()      # noqa: E731
+    adj = lambda y: orc.adjoint(og, y, **kw).astype(np.float32)              # noqa: E731
+    eps = 1e-6
+    for positivity in (False, True):
+        base, err0 = orc.sirt(fwd, adj, 32 ** 3, g["b"], 10, positivity=positivity, ground_truth=gt)
+        rng = np.random.default_rng(0)
+
+        def noisy(op):
+            def f(v):
+                r = op(v)
+                return (r + eps * np.max(np.abs(r)) * rng.standard_normal(r.size)).astype(np.float32)
+            return f
+        rec, err = orc.sirt(noisy(fwd), noisy(adj), 32 ** 3, g["b"], 10, positivity=positivity, ground_truth=gt)
+        a_max, a_l2 = rel_max(rec, base) / eps, rel_l2(rec, base) / eps
+        print("SIRT x10 (positivity=%s): iterate moves by %.1f x eps (rel-max), %.1f x eps (rel-L2); rms_error by %.2f x eps"
+              % (positivity, a_max, a_l2, np.max(np.abs(err - err0) / err0) / eps))
+        assert 1.0 < a_max < 10.0 and a_l2 < 5.0

@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 LIB_PATH = os.environ.get("TOMO_HIP_LIB") or os.path.join(_HERE, "libtomo_hip.so")   # override: development builds only
 POSE_STRIDE = 7
+GEOM_WIDE_ROWS = 1        # TOMO_GEOM_WIDE_ROWS of include/tomo.h
 COMM_ID_BYTES = 128
 
 _c_i64 = ctypes.c_int64
@@ -50,6 +51,7 @@ SIGNATURES = {
     "tomo_memset0": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_size_t]),
     "tomo_sync": (ctypes.c_int, [_c_vp]),
     "tomo_set_option": (ctypes.c_int, [_c_vp, ctypes.c_char_p, ctypes.c_int]),
+    "tomo_check_geometry": (ctypes.c_int, [ctypes.POINTER(TomoGeom), ctypes.POINTER(ctypes.c_int)]),
     "tomo_set_geometry": (ctypes.c_int, [_c_vp, ctypes.POINTER(TomoGeom)]),
     "tomo_forward": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp]),
     "tomo_adjoint": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp, ctypes.c_int]),

@@ -29,6 +29,7 @@ struct tomo_ctx {
     float *d_volpad = nullptr;
     size_t volpad_elems = 0;
     bool halo_dirty = true;
+    bool wide_rows = false;             // TOMO_GEOM_WIDE_ROWS: a padded x-row pitch >= 2^24 bytes -- the 24-bit-multiply kernels are not used
     const void *staged_src = nullptr;   // device pointer whose contents the padded copy currently holds
     int reuse_staged = 0;               // caller vouches: contents of staged_src unchanged since it was staged
     // per-projection constants (pinned host staging + device)

@@ -177,11 +177,26 @@ int tomo_ensure_red(tomo_ctx *ctx, size_t n)
     return TOMO_OK;
 }
 
+// Pure host check shared by tomo_set_geometry and callers without a context (tests run it on CPU).
+extern "C" int tomo_check_geometry(const tomo_geom *g, int *flags)
+{
+    if (flags) *flags = 0;
+    if (!g) return tomo_fail(nullptr, TOMO_ERR_ARG, "check_geometry: null geometry");
+    if (g->nx < 1 || g->ny < 1 || g->nz < 1 || g->ndx < 1 || g->ndz < 1 || !(g->step > 0.0) || !(g->det_y > g->src_y))
+        return tomo_fail(nullptr, TOMO_ERR_ARG, "set_geometry: non-positive shape/step or det_y <= src_y");
+    const size_t nxp = (size_t)g->nx + 2 * TOMO_HALO, nyp = (size_t)g->ny + 2 * TOMO_HALO, nzp = (size_t)g->nz + 2 * TOMO_HALO;
+    if (nxp * nyp * nzp >= ((size_t)1 << 31)) return tomo_fail(nullptr, TOMO_ERR_UNSUPPORTED, "set_geometry: padded volume exceeds 2^31 voxels");
+    // the SGPR-base kernels (k_fwd_v2, k_proj_grad_v2/_v3) form lane offsets with 24-bit multiplies: cell * (row pitch in bytes)
+    if (nyp * nzp * 4 >= ((size_t)1 << 24) || nzp * 4 >= ((size_t)1 << 24)) { if (flags) *flags |= TOMO_GEOM_WIDE_ROWS; }
+    return TOMO_OK;
+}
+
 extern "C" int tomo_set_geometry(tomo_ctx *ctx, const tomo_geom *g)
 {
     if (!ctx || !g) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
-    if (g->nx < 1 || g->ny < 1 || g->nz < 1 || g->ndx < 1 || g->ndz < 1 || !(g->step > 0.0) || !(g->det_y > g->src_y))
-        return tomo_fail(ctx, TOMO_ERR_ARG, "set_geometry: non-positive shape/step or det_y <= src_y");
+    int gflags = 0;
+    int grc = tomo_check_geometry(g, &gflags);
+    if (grc) return tomo_fail(ctx, grc, tomo_last_error(nullptr));
     ctx->tile_cache_valid = false;
     TomoGeomC c{};
     c.nx = g->nx; c.ny = g->ny; c.nz = g->nz; c.ndx = g->ndx; c.ndz = g->ndz;
@@ -190,7 +205,7 @@ extern "C" int tomo_set_geometry(tomo_ctx *ctx, const tomo_geom *g)
     c.det_x0 = g->det_x0; c.det_z0 = g->det_z0; c.det_dx = g->det_dx; c.det_dz = g->det_dz;
     c.src_y = g->src_y; c.det_y = g->det_y; c.step = g->step;
     size_t pe = (size_t)c.nxp * c.nyp * c.nzp;
-    if (pe >= ((size_t)1 << 31)) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "set_geometry: padded volume exceeds 2^31 voxels");
+    ctx->wide_rows = (gflags & TOMO_GEOM_WIDE_ROWS) != 0;
     TOMO_HIP(ctx, hipSetDevice(ctx->device));
     if (pe != ctx->volpad_elems) {
         TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));

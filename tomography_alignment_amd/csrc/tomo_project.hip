@@ -256,7 +256,7 @@ extern "C" int tomo_forward(tomo_ctx *ctx, const double *h_poses, int n_proj, co
         rc = upload_projc(ctx, h_poses + (size_t)p0 * TOMO_POSE_STRIDE, np, false, &d_pc, nullptr);
         if (rc) return rc;
         float *out = d_proj + (size_t)p0 * n_det;
-        if (ctx->fwd_variant == 1)
+        if (ctx->fwd_variant == 1 || ctx->wide_rows)      // wide rows: 24-bit offset multiplies would truncate (tomo_check_geometry)
             TOMO_LAUNCH(ctx, "k_fwd_v1", k_fwd_v1, ray_grid(g, np), dim3(256), 0, d_pc, ctx->d_volpad, out, g);
         else
             TOMO_LAUNCH(ctx, "k_fwd_v2", k_fwd_v2, ray_grid(g, np), dim3(256), 0, d_pc, ctx->d_volpad, out, g);
@@ -426,7 +426,7 @@ extern "C" int tomo_proj_grad(tomo_ctx *ctx, const double *h_pose, const float *
     int n_plain = 0;
     rc = upload_projc(ctx, h_pose, 1, true, &d_pc, &d_gc, nullptr, &n_plain);
     if (rc) return rc;
-    const int variant = ctx->grad_variant == 4 ? (n_plain ? 2 : 3) : ctx->grad_variant;       // 4 = by tilt
+    const int variant = ctx->wide_rows ? 1 : ctx->grad_variant == 4 ? (n_plain ? 2 : 3) : ctx->grad_variant;       // 4 = by tilt
     if (variant == 1)
         TOMO_LAUNCH(ctx, "k_proj_grad", k_proj_grad<false>, ray_grid(g, 1), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, d_proj, d_grad,
                     (const float *)nullptr, (float *)nullptr, (double *)nullptr, g, row_order);
@@ -467,7 +467,8 @@ extern "C" int tomo_cost_grad_rows(tomo_ctx *ctx, const double *h_poses, int n, 
     if (rc) return rc;
     TOMO_HIP(ctx, hipMemsetAsync(ctx->d_red, 0, sizeof(double) * (size_t)n * 7, ctx->stream));
     // up to two launches: the first group with one kernel variant, the second with another (grad_variant 4: v2 / v3 by tilt)
-    const int var_a = ctx->grad_variant == 4 ? 2 : ctx->grad_variant, var_b = ctx->grad_variant == 4 ? 3 : ctx->grad_variant;
+    const int var_a = ctx->wide_rows ? 1 : ctx->grad_variant == 4 ? 2 : ctx->grad_variant;
+    const int var_b = ctx->wide_rows ? 1 : ctx->grad_variant == 4 ? 3 : ctx->grad_variant;
     for (int part = 0; part < 2; ++part) {
         const int first = part == 0 ? 0 : n_plain, cnt = part == 0 ? n_plain : n - n_plain, variant = part == 0 ? var_a : var_b;
         if (cnt == 0) continue;

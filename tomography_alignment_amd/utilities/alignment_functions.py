@@ -5,9 +5,10 @@ Drop-in for the reference's utilities/alignment_functions.py:7-485: `AlignmentUt
 
 What is different underneath: one evaluation is ONE fused GPU kernel (tomo_cost_grad: projection +
 6-DoF Jacobian + residual + the 7 reductions) instead of a Fortran call followed by a 6 x n_det host
-GEMV, and the last evaluation is memoised so that an optimiser's `fun(x)` followed by `jac(x)` at the
-same point costs a single launch (the reference recomputes the whole projection_gradient for each,
-utilities/alignment_functions.py:151-188).  The vector-returning modes (`return_vector=True`) go
+GEMV.  Like the reference (utilities/alignment_functions.py:151-188) every call re-reads `rec`; when the
+caller pins the volume (`proj_obj.pin_volume(rec)`: "I will not modify it") it stays in HBM and the last
+evaluation is memoised, so that an optimiser's `fun(x)` followed by `jac(x)` at the same point costs a
+single launch.  The vector-returning modes (`return_vector=True`) go
 through `projection_gradient` exactly like the reference.
 
 Row order of the pose Jacobian everywhere: tx, ty, tz, phi, alpha, beta
@@ -60,10 +61,13 @@ class AlignmentUtilities(object):
         phi, alpha, beta = (float(v) for v in angles)
         t = np.asarray(translations, np.float64).reshape(3)
         po = self.proj_obj
-        key = (phi, alpha, beta, t[0], t[1], t[2], id(rec) if po.backend.is_buffer(rec) else np.asarray(rec).__array_interface__['data'][0])
+        # the memo (an optimiser's fun(x) followed by jac(x) at the same point = one launch) is only sound while the volume
+        # is pinned, i.e. the caller has promised not to change it; an unpinned `rec` is re-read on every call like the
+        # reference does (utilities/projection_operators.py:112-122)
+        memo_ok = hasattr(po, "volume_is_pinned") and po.volume_is_pinned(rec)
         vol = po.set_volume(rec)
-        key = key + (po._vol_key,)
-        if key == self._memo_key:
+        key = (phi, alpha, beta, t[0], t[1], t[2], po._vol_gen) if memo_ok else None
+        if key is not None and key == self._memo_key:
             return self._memo_val
         be = po.backend
         if self._b_dev is None:

@@ -182,9 +182,12 @@ class ProjectionMatrix(object):
         self.xyz_shift = None
         self.voxel_mask = None
         self._backend = backend
-        self._vol_key = None
-        self._vol_dev = None
-        self._vol_staged = False      # True once the library has staged the pinned volume and nothing has changed it since
+        self._vol_dev = None          # device buffer of the volume last passed to projection_gradient / cost_and_gradient
+        self._vol_own = False         # ... allocated here (host uploads) as opposed to handed in by the caller
+        self._vol_gen = 0             # bumped by every (re)load; memo keys carry it
+        self._pinned = None           # the object the caller pinned (identity), see pin_volume()
+        self._pin_stale = False
+        self._vol_staged = False      # True once the library has staged the PINNED volume and nothing has changed it since
         self._pg_bufs = None
 
     @property
@@ -224,44 +227,84 @@ class ProjectionMatrix(object):
         return weights, detector_inds, data_inds
 
     # ---- volume residency for repeated projection_gradient calls (alignment inner loop)
-    def set_volume(self, rec):
-        """Pin `rec` (host array or DeviceArray) in HBM for subsequent projection_gradient calls."""
+    # The reference recomputes from `rec` on every call (utilities/projection_operators.py:112-122), so by default so does
+    # this class: a host `rec` is uploaded and re-staged on EVERY call, a DeviceArray is re-staged on every call.  Keeping a
+    # volume resident across calls is explicit and opt-in: `pin_volume(rec)` (or `with P.pinned(rec):`) uploads / stages once
+    # and the caller promises not to modify `rec` until `unpin_volume()`; `invalidate_volume()` says "I did modify it".
+    # (An earlier version guessed from a fingerprint of a few samples whether a host array had changed; an in-place edit
+    # that missed the sampled elements then returned gradients of the old volume.)
+    def pin_volume(self, rec):
+        """Keep `rec` (host array or DeviceArray) resident in HBM: subsequent calls that pass this very object skip the
+        upload and the zero-padded staging.  The caller vouches that the contents do not change until unpin_volume() /
+        invalidate_volume()."""
+        self._pinned = None
+        vol = self._load_volume(rec)
+        self._pinned = rec
+        return vol
+
+    def unpin_volume(self):
+        self._pinned = None
+        self._vol_staged = False
+
+    def invalidate_volume(self):
+        """The pinned object's contents have changed: upload / stage again at the next call (it stays pinned)."""
+        self._pin_stale = True
+        self._vol_staged = False
+
+    def volume_is_pinned(self, rec):
+        return self._pinned is not None and rec is self._pinned and not self._pin_stale
+
+    def pinned(self, rec):
+        """Context manager form of pin_volume / unpin_volume."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            self.pin_volume(rec)
+            try:
+                yield self
+            finally:
+                self.unpin_volume()
+        return _cm()
+
+    def _load_volume(self, rec):
         be = self.backend
+        self._vol_gen += 1                      # every (re)load is a new generation: nothing derived from the old one is reused
+        self._vol_staged = False
+        self._pin_stale = False
         if be.is_buffer(rec):
-            if self._vol_key != ("dev", id(rec)):
-                self._vol_staged = False
-            self._vol_dev, self._vol_key = rec, ("dev", id(rec))
+            self._vol_dev = rec
+            self._vol_own = False
             return rec
-        a = np.asarray(rec)
-        flat = a.reshape(-1)
-        stride = max(1, flat.size // 4096)
-        key = (a.__array_interface__['data'][0], a.shape, str(a.dtype), float(np.sum(flat[::stride], dtype=np.float64)),
-               float(flat[-1]))
-        if key != self._vol_key:
-            if self._vol_dev is None or self._vol_key is None or self._vol_key[0] == "dev" or self._vol_dev.size != flat.size:
-                self._vol_dev = be.empty(flat.size)
-            self._vol_dev.upload(flat)
-            self._vol_key = key
-            self._vol_staged = False
+        flat = np.asarray(rec).reshape(-1)
+        if self._vol_dev is None or not self._vol_own or self._vol_dev.size != flat.size:
+            self._vol_dev = be.empty(flat.size)
+            self._vol_own = True
+        self._vol_dev.upload(flat)
         return self._vol_dev
 
+    def set_volume(self, rec):
+        """Device buffer holding `rec` for the next proj_grad / cost_grad call: the pinned copy if `rec` is the pinned
+        object, else a fresh upload (host array) / the buffer itself, to be re-staged (DeviceArray)."""
+        if self._pinned is not None and rec is self._pinned:
+            if self._pin_stale:
+                return self._load_volume(rec)
+            return self._vol_dev
+        return self._load_volume(rec)
+
     def pinned_call(self, fn, *args, **kw):
-        """Run a proj_grad / cost_grad backend call on the pinned volume, letting the library reuse its staged (zero-padded)
-        copy when the pinned contents have not changed since the last such call.  A DeviceArray passed by the caller is only
-        trusted between calls that pin the same object: whoever mutates it in place must call `invalidate_volume()`."""
+        """Run a proj_grad / cost_grad backend call on the volume set_volume() returned, letting the library reuse its
+        staged (zero-padded) copy only while an explicitly pinned volume is unchanged."""
         ctx = getattr(self.backend, "ctx", None)
         if ctx is None:
             return fn(*args, **kw)
-        ctx.set_option("reuse_staged_volume", 1 if self._vol_staged else 0)
+        ctx.set_option("reuse_staged_volume", 1 if (self._vol_staged and self._pinned is not None and not self._pin_stale) else 0)
         try:
             out = fn(*args, **kw)
-            self._vol_staged = True
+            self._vol_staged = self._pinned is not None
         finally:
             ctx.set_option("reuse_staged_volume", 0)
         return out
-
-    def invalidate_volume(self):
-        self._vol_staged = False
 
     def pose_row(self, alpha, beta, phi, xyz_shift, cor_shift):
         return _lib.poses_array([phi], [alpha], [beta], np.asarray(xyz_shift, np.float64).reshape(1, 3),
