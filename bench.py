@@ -1,26 +1,32 @@
 #!/usr/bin/env python3
 """
 bench.py -- headline benchmark of BASELINE.json: SIRT iterations/s on a 1024^3 volume x 1024 angles
-(parallel beam, Shepp-Logan, phi = linspace(0, pi)), with the forward / back-projection kernels priced
-against the MI355X HBM roofline.
+(parallel beam, Shepp-Logan, phi = linspace(0, pi)), with the dominant projector kernel priced against the
+resource that bounds it.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: this script spawns the N ranks itself)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (same result)
 
 One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment; torch is not imported).
 A "step" is one SIRT iteration: A.rec, residual, A^T(W*res), all-reduce of the voxel update over the
 angle shards (RCCL over xGMI; strong scaling: the 1024 angles are split across the N GPUs), update.
 Inputs are resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
 
-Extra objects in the line (see DESIGN.md, "Measurement"):
-  roofline     dominant kernel of the step: algorithmic bytes per launch / mean launch time (HIP events
-               recorded on the kernel's own stream inside the timed region) against 8 TB/s
-  cpu_baseline the CPU oracle (oracle/: plain-C port of the reference algorithm, 1 thread) timed on this
-               box's host cores on ONE angle of the same workload, extrapolated linearly in n_proj
+Extra objects in the line (DESIGN.md, "Measurement"):
+  roofline     the projector kernel that takes most of a step: counted work per launch (wave-instructions by unit,
+               LDS bytes, HBM bytes -- rocprofv3 PMC passes of THIS command, committed under profiles/) / mean launch time
+               measured live (HIP events on the kernel's own stream inside the timed region) against the unit's peak
+               (MI355X_MICROARCH.md); `bound` is the unit with the highest utilisation.  The algorithmic-HBM figure of
+               SURVEY 8d (volume re-read per angle) is kept as `hbm_algorithmic` -- it exceeds the HBM peak for the LDS-tile
+               kernels, which read the volume from HBM once per CALL, and is therefore not the roofline.
+  dense_volume the same SIRT step on a volume without zero regions (the tile kernels skip all-zero tiles; Shepp-Logan has many)
+  cpu_baseline the CPU oracle (oracle/: plain-C port of the reference algorithm) timed on this box's host cores on a bounded
+               sample of the same workload, extrapolated linearly in the number of rays / angles
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,15 +36,92 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+# MI355X peaks (MI355X_MICROARCH.md: chip-level parameters; LDS table; wave scheduling)
+HBM_PEAK_GBS = 8000.0         # HBM3E spec
+N_CU = 256
+CLK_GHZ = 2.4                 # max shader clock; the chip holds less under load, so fractions against it are conservative
+VALU_PEAK_GINSTR = N_CU * 4 * CLK_GHZ / 2.0      # one wave64 VALU instruction per 2 cycles per SIMD-32, 4 SIMDs per CU = 1228.8 G/s
+LDS_PEAK_GBS = N_CU * 128 * CLK_GHZ              # 128 B/clk/CU for ds_read_b32 / ds_read2_b32 / ds_read2st64_b32 = 78.6 TB/s ("~75 TB/s")
+# ... and what tools/issue_bench.hip measured on this chip with every CU issuing (clock as held under that load): the
+# practical ceilings, quoted beside the spec-derived ones
+VALU_MEASURED_GINSTR = 570.0  # v_fma_f32 573, v_readlane 519, v_pk_fma_f32 475, v_add_u32 773 G wave-instr/s (profiles/round2_issue_bench.log)
+LDS_MEASURED_GINSTR2 = 142.0  # ds_read2_b32 / ds_read2st64_b32 / ds_add_u32 / ds_write_b32: 142 G wave-instr/s = 72.7 TB/s at 512 B each
+
+
+def _count_gpus():
+    """Number of visible GPUs, found in a CHILD process: the launcher itself must never initialise HIP (it starts other
+    programs afterwards)."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import ctypes\n"
+            "from tomography_alignment_amd import _lib\n"
+            "n = ctypes.c_int(0)\n"
+            "rc = _lib.load().tomo_device_count(ctypes.byref(n))\n"
+            "print(n.value if rc == 0 else 0)\n") % ROOT
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 and out.stdout.strip() else 0
+    except (OSError, ValueError, subprocess.TimeoutExpired):
+        return 0
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: spawn N fresh rank processes (one per GPU) BEFORE this process makes any
+    HIP call, hand rank 0's JSON line through, exit non-zero if any rank does.  Replaces `mpirun -n N python ...` of the
+    reference's recon/sirt_mpi.py:36-72 workflow."""
+    import socket
+    visible = _count_gpus()
+    if visible < n:
+        sys.stderr.write("bench.py: %d GPUs requested, %d visible\n" % (n, visible))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                TOMO_RDV_KEY="bench_%d_%d" % (os.getpid(), int(time.time() * 1e3) & 0xffffff), NCCL_SOCKET_IFNAME=os.environ.get("NCCL_SOCKET_IFNAME", "lo"))
+    import tempfile
+    procs = []
+    out0 = tempfile.TemporaryFile()
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=None))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("TOMO_BENCH_LAUNCH_TIMEOUT", "3000"))
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                sys.stderr.write("bench.py: rank %d exited with code %s\n" % bad[0])
+                rc = 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                sys.stderr.write("bench.py: ranks still running at the launcher's time limit\n")
+                rc = 3
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()          # exactly the processes started here
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
+    out0.seek(0)
+    lines = [ln for ln in out0.read().decode(errors="replace").splitlines() if ln.strip()]
+    if rc == 0 and lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+        return 0
+    return rc or 1
 
 
 def main():
-    # Libraries (RCCL prints a version banner at communicator init) must not pollute the ONE JSON line on stdout:
-    # send everything written to fd 1 during the run to stderr and keep the real stdout for the final line.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -46,14 +129,25 @@ def main():
     ap.add_argument("--size", type=int, default=1024, help="volume edge N (N^3 voxels, N x N detector)")
     ap.add_argument("--angles", type=int, default=1024)
     ap.add_argument("--perturbed", action="store_true", help="alpha,beta ~ U(+-1 deg), tx,tz ~ U(+-2 px) (default_rng(0))")
+    ap.add_argument("--dense", action="store_true", help="headline on a volume without zero regions (no all-zero tile exits)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-align", action="store_true", help="skip the alignment-gradient evals/s side measurement (config 5)")
     ap.add_argument("--no-tilted", action="store_true", help="skip the tilted-pose SIRT side measurement")
+    ap.add_argument("--no-dense", action="store_true", help="skip the dense-volume SIRT side measurement")
     ap.add_argument("--force-sharded", action="store_true",
                     help="N=1 only: run the multi-GPU code path (sharded solver, x-slab pipelined all-reduce) on a 1-rank RCCL communicator")
     ap.add_argument("--fwd-variant", type=int, default=None)
     ap.add_argument("--adj-variant", type=int, default=None)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))          # nothing below has run: this process never touches the GPU
+
+    # Libraries (RCCL prints a version banner at communicator init) must not pollute the ONE JSON line on stdout:
+    # send everything written to fd 1 during the run to stderr and keep the real stdout for the final line.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     from tomography_alignment_amd import _lib
     from tomography_alignment_amd.backend import HipBackend
@@ -65,7 +159,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     N, n_proj = args.size, args.angles
     comm = RcclComm.from_env()
     ctx = comm.ctx
@@ -80,33 +174,49 @@ def main():
 
     geo = Geometry(n_proj, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
     phi = np.linspace(0., np.pi, n_proj)
-    alpha, beta, xyz = np.zeros(n_proj), np.zeros(n_proj), np.zeros((n_proj, 3))
-    if args.perturbed:
-        rng = np.random.default_rng(0)
-        alpha = np.deg2rad(rng.uniform(-1, 1, n_proj))
-        beta = np.deg2rad(rng.uniform(-1, 1, n_proj))
-        xyz[:, 0] = rng.uniform(-2, 2, n_proj)
-        xyz[:, 2] = rng.uniform(-2, 2, n_proj)
-    angles = np.array([phi, alpha, beta]).T
+
+    def poses_for(tilted):
+        alpha, beta, xyz = np.zeros(n_proj), np.zeros(n_proj), np.zeros((n_proj, 3))
+        if tilted:
+            rng = np.random.default_rng(0)
+            alpha = np.deg2rad(rng.uniform(-1, 1, n_proj))
+            beta = np.deg2rad(rng.uniform(-1, 1, n_proj))
+            xyz[:, 0] = rng.uniform(-2, 2, n_proj)
+            xyz[:, 2] = rng.uniform(-2, 2, n_proj)
+        return alpha, beta, xyz
 
     # ---- synthetic data, generated and kept on the device: phantom -> this rank's sinogram rows
     my_rows = np.array_split(np.arange(n_proj), world)[rank]
     shard_geo = sirt_mpi.SIRT._shard_geometry(geo, my_rows)
     be = HipBackend(shard_geo, ctx=ctx)
     d_true = be.phantom(be.empty(N ** 3), (N, N, N), SHEPP_LOGAN)
-    poses = _lib.poses_array(phi[my_rows], alpha[my_rows], beta[my_rows], xyz[my_rows], np.zeros(3))
-    d_b = be.forward(poses, d_true, be.empty(my_rows.size * N * N))
+    d_b = be.empty(my_rows.size * N * N)
     opts = {"_backend": be}
-    if world > 1 or args.force_sharded:
-        solver = sirt_mpi.SIRT(comm, geo, d_b, angles, xyz, opts)
-    else:
-        solver = sirt_mod.SIRT(geo, d_b, angles, xyz, opts)
+
+    def make_dense(vol):
+        """Shepp-Logan + 0.05 everywhere: same object, no voxel exactly zero (the zero-tile exits never fire)."""
+        one = be.empty(vol.size)
+        be.fill(one, 0.05)
+        be.axpy(vol, one, 1.0)
+        del one
+
+    def make_solver(tilted):
+        alpha, beta, xyz = poses_for(tilted)
+        poses = _lib.poses_array(phi[my_rows], alpha[my_rows], beta[my_rows], xyz[my_rows], np.zeros(3))
+        be.forward(poses, d_true, d_b)
+        angles = np.array([phi, alpha, beta]).T
+        if world > 1 or args.force_sharded:
+            return sirt_mpi.SIRT(comm, geo, d_b, angles, xyz, opts)
+        return sirt_mod.SIRT(geo, d_b, angles, xyz, opts)
 
     def barrier():
         ctx.sync()
         comm.barrier()
         ctx.sync()
 
+    if args.dense:
+        make_dense(d_true)
+    solver = make_solver(args.perturbed)
     if args.warmup > 0:
         solver.iterate_device(niter=args.warmup)
     barrier()
@@ -121,15 +231,20 @@ def main():
     if k_done != args.steps:
         raise SystemExit("bench.py: solver stopped after %d of %d steps (semi-convergence rule fired)" % (k_done, args.steps))
 
-    # ---- per-kernel timing of the timed region (HIP events on the ctx stream)
+    # ---- per-kernel timing of the timed region (HIP events on the stream each kernel / collective runs on)
     kern = {}
-    for name in ("k_fwd_v1", "k_fwd_v2", "k_fwd_tile", "k_fwd_tile_flat", "k_adj_v1", "k_adj_tile", "k_adj_tile_flat", "k_adj_gather_flat", "k_pad", "k_unpad", "k_absmax", "k_residual_scale", "k_update",
-                 "k_vec", "allreduce_f32"):
+    for name in ("k_fwd_v1", "k_fwd_v2", "k_fwd_tile", "k_fwd_tile_flat", "k_adj_v1", "k_adj_tile", "k_adj_tile_flat", "k_adj_gather_flat", "k_pad", "k_unpad",
+                 "k_absmax", "k_residual_scale", "k_update", "k_vec", "allreduce_f32", "comm_join_wait"):
         n, ms = ctx.profile_get(name)
         if n:
             # a pass over all angles may be issued as several launches (x slabs of the pipelined back-projection):
-            # ms_per_step sums them, so bytes-per-pass / ms_per_step == bytes-per-launch / avg launch time
+            # ms_per_step sums them, so work-per-pass / ms_per_step == work-per-launch / avg launch time
             kern[name] = {"launches": n, "avg_ms": ms / n, "launches_per_step": n / float(args.steps), "ms_per_step": ms / float(args.steps)}
+    if "allreduce_f32" in kern:
+        # bytes each rank hands to the collective per step (the voxel update, float32) and what a ring moves per rank for it
+        kern["allreduce_f32"]["bytes_per_step"] = 4.0 * N ** 3
+        kern["allreduce_f32"]["ring_bytes_per_rank_per_step"] = 2.0 * (world - 1) / world * 4.0 * N ** 3
+        kern["allreduce_f32"]["exposed_ms_per_step"] = kern.get("comm_join_wait", {}).get("ms_per_step", kern["allreduce_f32"]["ms_per_step"])
     n_loc = my_rows.size
     n_det = N * N
     alg_fwd = n_loc * (4.0 * N ** 3 + 4.0 * n_det)               # bytes per forward launch   
@@ -141,28 +256,20 @@ def main():
         cands.append((kern[fwd_name]["ms_per_step"], fwd_name, alg_fwd))
     if adj_name:
         cands.append((kern[adj_name]["ms_per_step"], adj_name, alg_adj))
+    key = "N%d_A%d_G%d%s%s" % (N, n_proj, world, "_P" if args.perturbed else "", "_D" if args.dense else "")
     roofline = None
     if cands:
         step_ms, name, alg = max(cands)
-        lps = kern[name]["launches_per_step"]
-        ach = alg / (step_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                    "algorithmic_bytes_per_launch": alg / lps, "avg_launch_ms": round(step_ms / lps, 3), "launches_per_step": lps}
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (counters cannot be
-        # collected from inside the timed run; see profiles/*_rocprof_summary.md for how they were taken/corrected)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pmc.get("key") == "N%d_A%d_G%d%s" % (N, n_proj, world, "_P" if args.perturbed else "") and name in pmc["kernels"]:
-                roofline["traffic"] = pmc["kernels"][name]["hbm_bytes_per_launch"] / lps
-                roofline["traffic_source"] = "profiles/pmc_traffic.json (%s)" % pmc.get("source", "")
-        except (OSError, ValueError, KeyError):
-            pass
+        roofline = make_roofline(name, step_ms, kern[name]["launches_per_step"], alg, key)
     extra = {}
     if fwd_name:
         extra["forward_alg_GBps"] = round(alg_fwd / (kern[fwd_name]["ms_per_step"] * 1e-3) / 1e9, 1)
     if adj_name:
         extra["backproj_alg_GBps"] = round(alg_adj / (kern[adj_name]["ms_per_step"] * 1e-3) / 1e9, 1)
+    # the other projector kernel, priced the same way (secondary)
+    if roofline is not None and len(cands) == 2:
+        o_ms, o_name, o_alg = min(cands)
+        extra["roofline_other_kernel"] = make_roofline(o_name, o_ms, kern[o_name]["launches_per_step"], o_alg, key)
 
     its = args.steps / elapsed
     out = {
@@ -177,9 +284,9 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (3-D Shepp-Logan generated on the device; sinogram = its forward projection)",
-        "config": {"workload": "SIRT %d^3 volume x %d angles, parallel beam, step 1.0, detector %dx%d%s"
-                               % (N, n_proj, N, N, ", perturbed poses" if args.perturbed else ""),
+        "data": "synthetic (3-D Shepp-Logan generated on the device%s; sinogram = its forward projection)" % (" + 0.05 everywhere" if args.dense else ""),
+        "config": {"workload": "SIRT %d^3 volume x %d angles, parallel beam, step 1.0, detector %dx%d%s%s"
+                               % (N, n_proj, N, N, ", perturbed poses" if args.perturbed else "", ", dense volume" if args.dense else ""),
                    "sharding": "angles split over %d GPU(s), RCCL all-reduce of the voxel update" % world,
                    "rms_error_last": float(rms[-1])},
         "roofline": roofline,
@@ -190,42 +297,100 @@ def main():
         step_alg = n_proj * (12.0 * N ** 3 + 8.0 * n_det) + 16.0 * n_proj * n_det + 16.0 * N ** 3
         out["sirt_step_alg_GBps"] = round(step_alg / (elapsed / args.steps) / 1e9, 1)
 
-    if not args.no_tilted and not args.perturbed:
-        # side measurement (not `value`): the same workload with tilted poses (alpha, beta ~ U(+-1 deg), tx, tz ~ U(+-2 px),
-        # default_rng(0) -- SURVEY 8d's perturbed run): these take the general tile kernels, which is what SIRT runs on
-        # once an alignment pass has moved the poses
+    def side_run(tilted, dense, label):
+        """2 timed iterations (1 warm-up) of the same workload with other poses / another volume: {value, unit, ...}."""
+        nonlocal solver
         del solver
-        rng = np.random.default_rng(0)
-        alpha_t, beta_t = np.deg2rad(rng.uniform(-1, 1, n_proj)), np.deg2rad(rng.uniform(-1, 1, n_proj))
-        xyz_t = np.zeros((n_proj, 3))
-        xyz_t[:, 0], xyz_t[:, 2] = rng.uniform(-2, 2, n_proj), rng.uniform(-2, 2, n_proj)
-        angles_t = np.array([phi, alpha_t, beta_t]).T
-        poses_t = _lib.poses_array(phi[my_rows], alpha_t[my_rows], beta_t[my_rows], xyz_t[my_rows], np.zeros(3))
-        be.forward(poses_t, d_true, d_b)
-        if world > 1 or args.force_sharded:
-            solver = sirt_mpi.SIRT(comm, geo, d_b, angles_t, xyz_t, opts)
-        else:
-            solver = sirt_mod.SIRT(geo, d_b, angles_t, xyz_t, opts)
+        if dense:
+            make_dense(d_true)
+        solver = make_solver(tilted)
         solver.iterate_device(niter=1)
         barrier()
-        t0 = time.perf_counter()
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        t1 = time.perf_counter()
         solver.iterate_device(niter=2)
         barrier()
-        dt = comm.allreduce_max(time.perf_counter() - t0)
-        out["tilted_poses"] = {"value": round(2.0 / dt, 6), "unit": "it/s", "steps": 2, "warmup": 1,
-                               "config": "same workload, alpha, beta ~ U(+-1 deg), tx, tz ~ U(+-2 px): general tile kernels"}
+        dt = comm.allreduce_max(time.perf_counter() - t1)
+        ctx.profile_enable(False)
+        kk = {}
+        for nm in ("k_fwd_tile", "k_fwd_tile_flat", "k_adj_tile", "k_adj_tile_flat", "k_adj_gather_flat"):
+            n, ms = ctx.profile_get(nm)
+            if n:
+                kk[nm + "_ms_per_step"] = round(ms / 2.0, 2)
+        return dict({"value": round(2.0 / dt, 6), "unit": "it/s", "steps": 2, "warmup": 1, "config": label}, **kk)
+
+    if not args.no_tilted and not args.perturbed and not args.dense:
+        # side measurement (not `value`): alpha, beta ~ U(+-1 deg), tx, tz ~ U(+-2 px), default_rng(0) -- SURVEY 8d's perturbed run:
+        # these take the general tile kernels, which is what SIRT runs on once an alignment pass has moved the poses
+        out["tilted_poses"] = side_run(True, False, "same workload, alpha, beta ~ U(+-1 deg), tx, tz ~ U(+-2 px): general tile kernels")
+    if not args.no_dense and not args.dense:
+        # side measurement: the same object + 0.05 everywhere, so that no tile is all zero (VERDICT r1: the headline leans on
+        # the zero-tile exits of the tile kernels; Shepp-Logan is exactly zero outside its ellipsoid)
+        out["dense_volume"] = side_run(args.perturbed, True, "same workload on a volume with no zero voxel (Shepp-Logan + 0.05): no all-zero tile exits")
     if not args.no_align:
         del solver
         out["alignment_gradient"] = align_rate(comm, ctx, rank, world, N=min(512, max(32, N // 2)), n_proj=720 if N >= 1024 else max(8, n_proj // 2))
     if roofline is not None:
         roofline["measured_d2d_copy_GBps"] = copy_probe(ctx, be)        # read + write of a 2 GiB hipMemcpy D2D, same run
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(be, d_true, N, n_proj, phi)
+        d_ref = be.phantom(be.empty(N ** 3), (N, N, N), SHEPP_LOGAN)
+        out["cpu_baseline"] = cpu_baseline(be, d_ref, N, n_proj, phi)
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or args.force_sharded:
         comm.close()
+
+
+def make_roofline(name, ms_per_step, launches_per_step, alg_bytes_per_pass, key):
+    """Utilisation of every unit that could bound `name`, from counted work per launch (committed rocprofv3 PMC passes of this
+    very command, profiles/sq_counters.json + profiles/pmc_traffic.json) and the live launch time; `bound` = the busiest unit.
+    Without counters for this workload: the algorithmic-HBM figure only, flagged `counters: null`."""
+    t = ms_per_step * 1e-3                                   # seconds per pass over all angles (sums the x-slab launches)
+    alg_gbs = alg_bytes_per_pass / t / 1e9
+    r = {"kernel": name, "avg_launch_ms": round(ms_per_step / launches_per_step, 3), "launches_per_step": launches_per_step,
+         "hbm_algorithmic": {"bytes_per_launch": alg_bytes_per_pass / launches_per_step, "GBps": round(alg_gbs, 1), "frac_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4),
+                             "note": "SURVEY 8d byte model (volume re-read per angle); the LDS-tile kernels read the volume once per call, so this is not a roofline for them"},
+         "traffic": None, "counters": None}
+    sq, pmc = None, None
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))
+        if j.get("key") == key and name in j["kernels"]:
+            sq = j["kernels"][name]
+            r["counters"] = {"source": "profiles/sq_counters.json (%s)" % j.get("source", ""), "per_pass": sq}
+    except (OSError, ValueError, KeyError):
+        pass
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if j.get("key") == key and name in j["kernels"]:
+            pmc = j["kernels"][name]["hbm_bytes_per_launch"]
+            r["traffic"] = pmc / launches_per_step
+            r["traffic_source"] = "profiles/pmc_traffic.json (%s)" % j.get("source", "")
+    except (OSError, ValueError, KeyError):
+        pass
+    util = {}
+    if pmc is not None:
+        util["hbm"] = (pmc / t / 1e9, HBM_PEAK_GBS, "GB/s")
+    if sq is not None:
+        if sq.get("SQ_INSTS_VALU"):
+            util["valu_issue"] = (sq["SQ_INSTS_VALU"] / t / 1e9, VALU_PEAK_GINSTR, "Ginstr/s")
+        if sq.get("lds_bytes"):
+            util["lds"] = (sq["lds_bytes"] / t / 1e9, LDS_PEAK_GBS, "GB/s")
+    if not util:
+        # no counters for this exact workload: fall back to the algorithmic-HBM figure, capped reading left to the consumer
+        r.update({"bound": "hbm", "achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 4),
+                  "note": "no committed PMC counters for workload key %s: algorithmic-HBM figure (may exceed 1 for the LDS-tile kernels)" % key})
+        return r
+    bound = max(util, key=lambda k: util[k][0] / util[k][1])
+    ach, peak, unit = util[bound]
+    r.update({"bound": bound, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": unit, "frac": round(ach / peak, 4),
+              "utilisation": {k: {"achieved": round(v[0], 1), "peak": round(v[1], 1), "unit": v[2], "frac": round(v[0] / v[1], 4)} for k, v in util.items()}})
+    if "valu_issue" in util:
+        r["utilisation"]["valu_issue"]["frac_of_measured_ceiling"] = round(util["valu_issue"][0] / VALU_MEASURED_GINSTR, 4)
+    if "lds" in util:
+        r["utilisation"]["lds"]["frac_of_measured_ceiling"] = round(util["lds"][0] / (LDS_MEASURED_GINSTR2 * 512.0), 4)
+    return r
 
 
 def align_rate(comm, ctx, rank, world, N=512, n_proj=720, passes=3):
@@ -252,25 +417,36 @@ def align_rate(comm, ctx, rank, world, N=512, n_proj=720, passes=3):
     # the untilted start is reported beside it.
     near = _lib.poses_array(phi[mine], alpha[mine] + np.deg2rad(0.5), beta[mine] - np.deg2rad(0.5), xyz[mine] + np.array([1.0, 0.0, -1.0]), np.zeros(3))
     start = _lib.poses_array(phi[mine], 0 * alpha[mine], 0 * beta[mine], 0 * xyz[mine], np.zeros(3))
-    rates = {}
-    for tag, poses in (("near_truth", near), ("start", start)):
-        be.cost_grad(poses, vol, b)
+    alg = 4.0 * N ** 3 + 4.0 * N * N + 28.0                      # fused form, BASELINE.md section 3
+
+    def rate(poses, volume):
+        be.cost_grad(poses, volume, b)
         ctx.sync()
         comm.barrier()
         t0 = time.perf_counter()
         for _ in range(passes):
-            cost, g6 = be.cost_grad(poses, vol, b)
+            cost, g6 = be.cost_grad(poses, volume, b)
         ctx.sync()
         comm.barrier()
         dt = comm.allreduce_max(time.perf_counter() - t0)
-        rates[tag] = (passes * n_proj / dt, float(cost[0]))
-    rate = rates["near_truth"][0]
-    alg = 4.0 * N ** 3 + 4.0 * N * N + 28.0                      # fused form, BASELINE.md section 3
-    return {"evals_per_sec": round(rate, 1), "unit": "evals/s", "config": "%d^3 volume, %d projections simulated with +-2 deg / +-5 px pose "
-            "errors, fused cost+6-DoF gradient evaluated 0.5 deg / 1 px away from the true poses" % (N, n_proj),
-            "alg_GBps": round(rate * alg / 1e9, 1), "frac_of_hbm_peak": round(rate * alg / 1e9 / HBM_PEAK_GBS, 4),
-            "evals_per_sec_at_untilted_start": round(rates["start"][0], 1),
-            "projections_per_launch": int(mine.size), "cost_first": rates["near_truth"][1], "cost_first_at_start": rates["start"][1]}
+        return passes * n_proj / dt, float(cost[0])
+
+    r_near, c_near = rate(near, vol)
+    r_start, c_start = rate(start, vol)
+    out = {"evals_per_sec": round(r_near, 1), "unit": "evals/s", "config": "%d^3 volume, %d projections simulated with +-2 deg / +-5 px pose "
+           "errors, fused cost+6-DoF gradient evaluated 0.5 deg / 1 px away from the true poses" % (N, n_proj),
+           "alg_GBps": round(r_near * alg / 1e9, 1), "frac_of_hbm_peak": round(r_near * alg / 1e9 / HBM_PEAK_GBS, 4),
+           "evals_per_sec_at_untilted_start": round(r_start, 1),
+           "projections_per_launch": int(mine.size), "cost_first": c_near, "cost_first_at_start": c_start}
+    # the same evaluation on a volume without zero voxels (the gradient kernels clip every ray to the bounding box of the
+    # non-zero voxels; Shepp-Logan fills about half of its cube)
+    dense = be.empty(N ** 3)
+    be.fill(dense, 0.05)
+    be.axpy(dense, vol, 1.0)
+    r_dense, _ = rate(near, dense)
+    out["dense_volume"] = {"evals_per_sec": round(r_dense, 1), "frac_of_hbm_peak": round(r_dense * alg / 1e9 / HBM_PEAK_GBS, 4),
+                           "config": "same poses and measured projections, volume = Shepp-Logan + 0.05 (no zero voxel)"}
+    return out
 
 
 def _cpu_share():
@@ -292,37 +468,49 @@ def _cpu_share():
 
 
 def cpu_baseline(be, d_true, N, n_proj, phi):
-    """Time the CPU oracle (plain-C port of the reference algorithm) on a bounded sample of the same workload, forward +
-    adjoint, extrapolated linearly in n_proj: (i) ONE thread, like the reference's serial Fortran, on one projection angle;
-    (ii) all host cores (OpenMP over rays) on a few angles."""
+    """Time the CPU oracle (plain-C port of the reference algorithm; 2-3x FASTER than the reference's own Fortran on the same
+    core) on a bounded sample of the same workload, forward + exact adjoint:
+      value      ONE thread, like the reference's serial Fortran: every 8th detector row of 2 angles (an unbiased 1/8 sample
+                 of their rays), extrapolated linearly in rays and angles;
+      all_cores  OpenMP over rays on the box's CPU share: 16 whole angles, extrapolated linearly in angles."""
     from oracle import oracle as orc
     x = be.download(d_true)
-    lib = orc._lib()
     n_cpu = _cpu_share()
-
-    def one(n_ang, threads):
-        lib.orc_set_threads(int(threads))
+    orc.set_threads(1)
+    og1 = orc.Geo(1, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
+    rows = np.arange(3, N, 8)
+    ray_idx = (rows[:, None] * N + np.arange(N)[None, :]).ravel()
+    frac = ray_idx.size / float(N * N)
+    picks = [n_proj // 3, (2 * n_proj) // 3 + 1]             # generic (non axis-aligned) angles
+    tf = ta = 0.0
+    for ip in picks:
+        t0 = time.perf_counter()
+        ax = orc.forward_rays(og1, x, phi[ip], ray_idx)
+        t1 = time.perf_counter()
+        orc.adjoint_rays(og1, ax.astype(np.float32), phi[ip], ray_idx)
+        t2 = time.perf_counter()
+        tf += (t1 - t0) / frac / len(picks)
+        ta += (t2 - t1) / frac / len(picks)
+    out = {"value": round(1.0 / ((tf + ta) * n_proj), 8), "unit": "it/s", "cores": 1, "kind": "port",
+           "sample": "every 8th detector row of %d of %d angles of the same %d^3 workload on one host core (forward %.1f s + exact adjoint %.1f s per "
+                     "whole angle), extrapolated linearly in rays and angles" % (len(picks), n_proj, N, tf, ta),
+           "host_cpus": os.cpu_count(), "cpu_share": n_cpu,
+           "calibration": "the oracle runs 2-3x faster than the reference's own flang-built Fortran on one core (BASELINE.md section 4)"}
+    if n_cpu > 1:
+        n_ang = 16 if n_cpu >= 8 else 2
+        orc.set_threads(n_cpu)
         og = orc.Geo(n_ang, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
-        ph = phi[n_proj // 3: n_proj // 3 + n_ang]           # generic (non axis-aligned) angles
+        ph = phi[n_proj // 3: n_proj // 3 + n_ang]
         t0 = time.perf_counter()
         ax = orc.forward(og, x, phi=ph)
         t1 = time.perf_counter()
-        orc.adjoint(og, ax.astype(np.float32), phi=ph, coloured_rows=threads > 1)     # threads own whole detector rows: no atomics
+        orc.adjoint(og, ax.astype(np.float32), phi=ph, coloured_rows=True)     # threads own whole detector rows: no atomics
         t2 = time.perf_counter()
-        return (t1 - t0) / n_ang, (t2 - t1) / n_ang
-
-    f1, a1 = one(1, 1)
-    out = {"value": round(1.0 / ((f1 + a1) * n_proj), 8), "unit": "it/s", "cores": 1, "kind": "port",
-           "sample": "1 of %d angles of the same %d^3 workload (forward %.1f s + adjoint %.1f s on one host core), "
-                     "extrapolated linearly in n_proj" % (n_proj, N, f1, a1),
-           "host_cpus": os.cpu_count(), "cpu_share": n_cpu}
-    if n_cpu > 1:
-        n_ang = 2 if n_cpu >= 8 else 1
-        fa, aa = one(n_ang, n_cpu)
+        fa, aa = (t1 - t0) / n_ang, (t2 - t1) / n_ang
         out["all_cores"] = {"value": round(1.0 / ((fa + aa) * n_proj), 8), "unit": "it/s", "cores": n_cpu,
-                            "sample": "%d of %d angles (forward %.2f s + adjoint %.2f s per angle on %d threads, OpenMP over rays)"
+                            "sample": "%d of %d whole angles (forward %.2f s + adjoint %.2f s per angle on %d threads, OpenMP over rays)"
                                       % (n_ang, n_proj, fa, aa, n_cpu)}
-    lib.orc_set_threads(1)
+    orc.set_threads(1)
     return out
 
 

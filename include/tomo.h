@@ -106,8 +106,8 @@ TOMO_API int tomo_set_option(tomo_ctx *ctx, const char *key, int value);
 /* Geometry: replaces passing a `Geometry` object to utilities/ray_voxel_utilities.py:53,113.
  * tomo_check_geometry is the validation tomo_set_geometry applies, callable without a context or a GPU: TOMO_ERR_ARG for
  * non-positive shapes / step or det_y <= src_y, TOMO_ERR_UNSUPPORTED for a zero-padded volume of 2^31 voxels or more;
- * *flags (nullable) receives TOMO_GEOM_* bits: WIDE_ROWS = one padded x-row ((ny+4)*(nz+4) floats) spans 2^24 bytes or
- * more (a slab such as 16 x 4096 x 4096), for which the ray-driven kernels with 24-bit offset multiplies (fwd_variant 2,
+ * *flags (nullable) receives TOMO_GEOM_* bits: WIDE_ROWS = one padded x-row ((ny+4)*(nz+4) floats) spans 2^23 bytes or
+ * more (a slab such as 16 x 2048 x 2048), for which the ray-driven kernels with 24-bit offset multiplies (fwd_variant 2,
  * grad_variant 2-4) are replaced by their plain 64-bit-indexing twins (variant 1) -- same results, slower. */
 #define TOMO_GEOM_WIDE_ROWS 1
 TOMO_API int tomo_check_geometry(const tomo_geom *g, int *flags);
@@ -203,6 +203,21 @@ TOMO_API int tomo_vec_sub(tomo_ctx *ctx, float *d_out, const float *d_a, const f
 TOMO_API int tomo_vec_mul(tomo_ctx *ctx, float *d_y, const float *d_x, int64_t n);                     /* y *= x */
 TOMO_API int tomo_vec_dot(tomo_ctx *ctx, const float *d_a, const float *d_b, int64_t n, double *h_dot);
 TOMO_API int tomo_vec_diff_sumsq(tomo_ctx *ctx, const float *d_a, const float *d_b, int64_t n, double *h_sumsq);
+
+/* ---------------------------------------------------------------- regularised solvers' vector kernels
+ * tomo_vec_soft_threshold: out = x - l where x > l, x + l where x < -l, else 0 -- recon/regularized.py:433-440
+ *   soft_thresholding (the proximal step of run_lasso_ista :278, its line search :321, run_lasso_fista :375).  out may alias x.
+ * tomo_tv_denoise_fista: utilities/tv_denoise.py:98-170 denoise_fista on a float32 volume [nx][ny][nz] resident in HBM (the TV
+ *   proximal step of recon/regularized.py:93): argmin 0.5*||im - res||^2 + weight*TV(res) by FISTA on the dual, with the
+ *   reference's helpers gradient (:34-59, forward differences, 0 at the last index), div (:20-31), _projector_on_dual (:67-75) and
+ *   dual_gap (:78-95).  d_out receives `new` exactly as the reference returns it: the iterate of the LAST GAP CHECK (every
+ *   check_gap_frequency iterations; the loop leaves as soon as the dual gap < eps), or a copy of im when niter = 0.
+ *   *h_iters = iterations completed, *h_dual_gap = the last gap evaluated (both nullable).  Every axis >= 2.
+ * tomo_tv_norm_3d: utilities/tv_denoise.py:62-64 tv_norm_3d = ||gradient(x)||_2 (used at recon/regularized.py:107). */
+TOMO_API int tomo_vec_soft_threshold(tomo_ctx *ctx, float *d_out, const float *d_x, int64_t n, float lambda);
+TOMO_API int tomo_tv_denoise_fista(tomo_ctx *ctx, const float *d_im, float *d_out, int nx, int ny, int nz, double weight, int niter, double eps,
+                          int check_gap_frequency, int *h_iters, double *h_dual_gap);
+TOMO_API int tomo_tv_norm_3d(tomo_ctx *ctx, const float *d_x, int nx, int ny, int nz, double *h_norm);
 
 /* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI)
  * Replaces mpi4py COMM_WORLD Allreduce(SUM) of recon/sirt_mpi.py:68,103 and recon/cgls_mpi.py:55,98

@@ -1,6 +1,7 @@
 #!/usr/bin/env bash
 # TEST INFRASTRUCTURE - builds the *untouched* reference Fortran where it lies
-# under /root/reference into oracle/_ref/ (git-ignored, travels with gpurun).
+# under /root/reference into oracle/_ref/ (git-ignored AND listed in .gpurunignore: compiled reference
+# objects stay in the authoring container; the GPU box gets the oracle restatement and the committed fixtures only).
 # Nothing from the reference is copied into the repo; only compiled objects and
 # f2py-GENERATED wrapper sources land in oracle/_ref/.
 #

@@ -257,6 +257,33 @@ def adjoint(geo, y, alpha=None, beta=None, phi=None, xyz_shift=None, coloured_ro
     return vol
 
 
+def _ray_subset(geo, phi, ray_index, alpha=0.0, beta=0.0, xyz_shift=None):
+    p0, rhat, n, _, _, _ = ray_setup(geo, alpha, beta, phi, np.zeros(3) if xyz_shift is None else xyz_shift, geo.cor_shift[0])
+    idx = np.asarray(ray_index, np.int64)
+    return np.ascontiguousarray(p0[:, idx]), np.ascontiguousarray(rhat[:, idx]), n, idx
+
+
+def forward_rays(geo, rec, phi, ray_index, **kw):
+    """A x restricted to the rays `ray_index` of one projection (same loop as forward(); bench.py times a fraction of an
+    angle's rays on one thread with it)."""
+    p0, rhat, n, idx = _ray_subset(geo, phi, ray_index, **kw)
+    nx, ny, nz = (int(v) for v in geo.vox_shape)
+    rec = np.ascontiguousarray(rec, dtype=np.float32).ravel()
+    out = np.zeros(idx.size, np.float64)
+    _lib().orc_forward(_p(p0), _p(rhat), ctypes.c_int64(idx.size), n, ctypes.c_double(geo.step_size), nx, ny, nz, _p(rec), _p(out))
+    return out
+
+
+def adjoint_rays(geo, y, phi, ray_index, **kw):
+    """A^T y restricted to the rays `ray_index` of one projection (y holds their values)."""
+    p0, rhat, n, idx = _ray_subset(geo, phi, ray_index, **kw)
+    nx, ny, nz = (int(v) for v in geo.vox_shape)
+    y = np.ascontiguousarray(y, dtype=np.float32).ravel()
+    vol = np.zeros(geo.n_vox, np.float64)
+    _lib().orc_adjoint(_p(p0), _p(rhat), ctypes.c_int64(idx.size), n, ctypes.c_double(geo.step_size), nx, ny, nz, _p(y), _p(vol))
+    return vol
+
+
 # ----------------------------------------------------------------------------------------
 # A2+A4: projection + 6-DoF gradient (utilities/projection_operators.py:112-122)
 # ----------------------------------------------------------------------------------------
@@ -456,6 +483,89 @@ def cgls(fwd, adj, n_vox, projections, niter, ground_truth=None, rec=None):
                   else np.linalg.norm(rec - np.asarray(ground_truth).ravel()) / norm_factor)
         k += 1
     return rec, rms[:k]
+
+
+# ----------------------------------------------------------------------------------------
+# regularised solvers' vector kernels: recon/regularized.py:433-440, utilities/tv_denoise.py
+# ----------------------------------------------------------------------------------------
+def soft_thresholding(x, lam):
+    """recon/regularized.py:433-440: shrink towards zero by lam (zero inside [-lam, lam])."""
+    x = np.asarray(x)
+    out = np.zeros_like(x)
+    up, dn = x > lam, x < -lam
+    out[up] = x[up] - lam
+    out[dn] = x[dn] + lam
+    return out
+
+
+def tv_gradient(img):
+    """utilities/tv_denoise.py:34-59: forward differences along every axis, zero at an axis' last index."""
+    g = np.zeros((img.ndim,) + img.shape, dtype=img.dtype)
+    for d in range(img.ndim):
+        dst = [slice(None)] * img.ndim
+        dst[d] = slice(None, -1)
+        g[d][tuple(dst)] = np.diff(img, axis=d)
+    return g
+
+
+def tv_div(grad):
+    """utilities/tv_denoise.py:20-31: negative adjoint of tv_gradient, accumulated axis by axis in the reference's order
+    (res[:-1] += g[:-1]; res[1:-1] -= g[:-2]; res[-1] -= g[-2])."""
+    res = np.zeros(grad.shape[1:], dtype=grad.dtype)
+    for d in range(grad.shape[0]):
+        g = np.moveaxis(grad[d], d, 0)
+        r = np.moveaxis(res, d, 0)           # a view: the in-place updates land in res
+        r[:-1] += g[:-1]
+        r[1:-1] -= g[:-2]
+        r[-1] -= g[-2]
+    return res
+
+
+def tv_norm_3d(x):
+    """utilities/tv_denoise.py:62-64."""
+    return np.linalg.norm(tv_gradient(x))
+
+
+def tv_dual_gap(im, new, gap, weight):
+    """utilities/tv_denoise.py:78-95 (3-D branch)."""
+    im_norm = (im ** 2).sum()
+    g = tv_gradient(new)
+    tv_new = 2 * weight * np.sqrt(g[0] ** 2 + g[1] ** 2 + g[2] ** 2).sum()
+    return 0.5 / im_norm * ((gap ** 2).sum() + tv_new - im_norm + (new ** 2).sum())
+
+
+def tv_denoise_fista(im, weight=50, niter=200, eps=1.e-5, check_gap_frequency=3, return_info=False):
+    """utilities/tv_denoise.py:98-170 for a 3-D volume: FISTA on the dual of 0.5*||im - res||^2 + weight*TV(res).  Returns
+    `new` as the reference does -- the iterate of the LAST dual-gap check (every check_gap_frequency iterations)."""
+    im = np.asarray(im)
+    assert im.ndim == 3
+    factor = 12.0                                                      # :139-142
+    grad_im = np.zeros((3,) + im.shape, dtype=im.dtype)
+    grad_aux = np.zeros((3,) + im.shape, dtype=im.dtype)
+    t, i, dgap = 1., 0, 0.0
+    new = im.copy()
+    while i < niter:
+        error = weight * tv_div(grad_aux) - im                         # :151
+        grad_tmp = tv_gradient(error)
+        grad_tmp *= 1 / (factor * weight)                              # :153
+        grad_aux += grad_tmp
+        norm = np.maximum(np.sqrt(np.sum(grad_aux ** 2, 0)), 1.)       # :67-75 projection on the unit ball, in place
+        for comp in grad_aux:
+            comp /= norm
+        grad_tmp = grad_aux
+        t_new = 0.5 * (1 + np.sqrt(1 + 4 * t ** 2))
+        t_factor = (t - 1) / t_new
+        grad_aux = (1 + t_factor) * grad_tmp - t_factor * grad_im      # :158
+        grad_im = grad_tmp
+        t = t_new
+        if (i % check_gap_frequency) == 0:                             # :161-166
+            gap = weight * tv_div(grad_im)
+            new = im - gap
+            dgap = tv_dual_gap(im, new, gap, weight)
+            if dgap < eps:
+                break
+        i += 1
+    return (new, i, float(dgap)) if return_info else new
 
 
 # ----------------------------------------------------------------------------------------

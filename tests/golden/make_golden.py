@@ -306,7 +306,33 @@ def g8():
     save("g8_voxel_splat", **out)
 
 
+# ------------------------------------------------------------------ G9 regularised solvers' vector kernels
+def g9():
+    """recon/regularized.py:433 soft_thresholding and utilities/tv_denoise.py denoise_fista / tv_norm_3d."""
+    from recon import regularized
+    from utilities import tv_denoise
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(4096).astype(np.float32)
+    x[::17] = 0.3                      # exactly +-lambda: the strict comparisons send these to zero
+    x[5::17] = -0.3
+    out = dict(st_x=x, st_lambda=np.array(0.3), st_out=regularized.soft_thresholding(x, np.float32(0.3)))
+    shape = (16, 12, 20)
+    vol = np.zeros(shape, np.float32)
+    vol[4:12, 3:9, 5:15] = 1.0
+    vol[6:9, 5:8, 8:12] = 0.4
+    noisy = (vol + 0.15 * rng.standard_normal(shape)).astype(np.float32)
+    out.update(tv_im=noisy, tv_norm=np.array(tv_denoise.tv_norm_3d(noisy)))
+    # (a) fixed number of iterations (eps = 0 never stops early; niter = 20 ends two iterations after the last gap check)
+    out["tv_a"] = tv_denoise.denoise_fista(noisy, weight=0.2, niter=20, eps=0.0, check_gap_frequency=3)
+    # (b) the dual-gap stop fires
+    out["tv_b"] = tv_denoise.denoise_fista(noisy, weight=0.05, niter=200, eps=1.e-3, check_gap_frequency=3)
+    # (c) gap checked every iteration, niter = 1
+    out["tv_c"] = tv_denoise.denoise_fista(noisy, weight=0.5, niter=1, eps=0.0, check_gap_frequency=1)
+    out["tv_d"] = tv_denoise.denoise_fista(noisy, weight=0.5, niter=0)
+    save("g9_regularized", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g7", "g1", "g2", "g3", "g4", "g5", "g6", "g8"]
+    which = sys.argv[1:] or ["g7", "g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9"]
     for w in which:
         globals()[w]()

@@ -58,15 +58,43 @@ def test_angle_split_is_the_reference_split():
     assert sh.n_proj == 2 and np.array_equal(sh.cor_shift, geo.cor_shift[6:8]) and geo.n_proj == 10
 
 
-def test_id_rendezvous_between_processes(tmp_path):
-    """The ncclUniqueId hand-off of RcclComm.from_env (rank 0 publishes, the others poll), with plain bytes."""
+def test_id_rendezvous_between_processes():
+    """The ncclUniqueId hand-off of RcclComm.from_env (rank 0 serves it on a loopback port, the others fetch it), with plain
+    bytes -- and a listener left behind by an EARLIER launch (another key) on the first candidate port, which must be told
+    apart and skipped (a stale id must never be read)."""
+    from tomography_alignment_amd import comm as tcomm
+    base = _free_port()
+    stale = socket.socket()
+    try:
+        stale.bind(("127.0.0.1", tcomm.candidate_ports(base)[0]))
+    except OSError:
+        pytest.skip("candidate port taken")
+    stale.listen(8)
+    import threading
+
+    def stale_server():                 # answers like a crashed launch's rank 0 would: with its own (old) id, for its own key only
+        stale.settimeout(60)
+        try:
+            while True:
+                c, _ = stale.accept()
+                try:
+                    n = int.from_bytes(c.recv(4), "little")
+                    key = c.recv(n)
+                    c.sendall(b"OK" + (128).to_bytes(4, "little") + bytes(128) if key == b"old" else b"NO")
+                finally:
+                    c.close()
+        except OSError:
+            pass
+    th = threading.Thread(target=stale_server, daemon=True)
+    th.start()
     code = ("import sys, os; sys.path.insert(0, %r)\n"
             "from tomography_alignment_amd.comm import exchange_from_rank0\n"
             "r = int(os.environ['RANK'])\n"
-            "got = exchange_from_rank0(r, 3, lambda: bytes(range(128)), timeout=60, directory=%r, key='t')\n"
-            "assert got == bytes(range(128)); print('ok', r)\n") % (ROOT, str(tmp_path))
+            "got = exchange_from_rank0(r, 3, lambda: bytes(range(128)), timeout=60, key='t', port=%d)\n"
+            "assert got == bytes(range(128)); print('ok', r)\n") % (ROOT, base)
     procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(os.environ, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-             for r in (2, 1, 0)]      # the pollers start first
+             for r in (2, 1, 0)]      # the fetchers start first
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    stale.close()
     assert all(p.returncode == 0 for p in procs), outs
     assert sorted(o.strip() for o in outs) == ["ok 0", "ok 1", "ok 2"]

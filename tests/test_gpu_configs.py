@@ -134,10 +134,14 @@ def test_config5_projection_gradient_512_all_variants(c5, capsys):
                   "within 2e-5 voxel of a cell face excluded; all rays: %.2e)" % (v, c5["pick"][k], e_p, e_g, 100 * frac, e_g_all))
     for v, k, e_p, e_g, e_g_all, frac in rows:
         assert e_p < TOL and e_g < TOL and frac < 0.10, (v, k, e_p, e_g, frac)
-    # the variants compute the same sums from the same float32 sample positions (same cells for every sample)
+    # variants 2-4 walk the same wave-uniform sample blocks (same float32 positions, same cell for every sample): identical sums
+    # on every ray; variant 1 anchors its blocks per ray, so a sample ON a cell face may fall on the other side -- compared on
+    # the well-conditioned rays only
     for k in range(3):
-        for v in (2, 3):
-            assert rel_max(per_variant[v, k][0], per_variant[1, k][0]) < 5e-6 and rel_max(per_variant[v, k][1], per_variant[1, k][1]) < 5e-6
+        ok = c5["ref"][k][2] > 2e-5
+        assert rel_max(per_variant[3, k][1], per_variant[2, k][1]) < 2e-6 and rel_max(per_variant[3, k][0], per_variant[2, k][0]) < 2e-6
+        assert rel_max(per_variant[2, k][0], per_variant[1, k][0]) < 5e-6
+        assert rel_max(per_variant[2, k][1][:, ok], per_variant[1, k][1][:, ok]) < 5e-6
 
 
 def test_config5_fused_cost_gradient_rows_512(c5, capsys):

@@ -432,7 +432,7 @@ def test_gradient_kernels_idle_lane_addressing(PM, orc, case):
     elif case == "lane63_only_tilted":
         alpha, beta, t = np.deg2rad(3.0), np.deg2rad(-2.0), np.array([0.3, 0.2, -35.2])
     elif case == "one_row_tilted":
-        shape, ndet, alpha, beta, t = (6, 6, 70), (30, 130), np.deg2rad(-4.0), np.deg2rad(5.0), np.array([-9.5, 0.0, 2.0])
+        shape, ndet, alpha, beta, t = (24, 24, 70), (60, 130), np.deg2rad(-4.0), np.deg2rad(5.0), np.array([-14.5, 0.0, 2.0])
     rng = np.random.default_rng(63)
     geo, og = geo_pair(1, None, ndet=ndet, shape=shape)
     x = rng.uniform(0.1, 1, shape).astype(np.float32)
@@ -461,7 +461,7 @@ def test_gradient_kernels_idle_lane_addressing(PM, orc, case):
         two = np.ascontiguousarray(np.repeat(pose, 2, axis=0))
         two[1, 5] += 200.0                                # second pose of the fused launch misses the volume entirely
         cost, g6 = be.cost_grad(two, be.upload(x), be.upload(np.concatenate([b, b])))
-        assert np.isclose(cost[0], 0.5 * np.dot(res, res), rtol=1e-6) and np.isclose(cost[1], 0.5 * np.dot(b.astype(np.float64), b), rtol=1e-6)
+        assert np.isclose(cost[0], 0.5 * np.dot(res, res), rtol=1e-5) and np.isclose(cost[1], 0.5 * np.dot(b.astype(np.float64), b), rtol=1e-5)
         want6 = -np.dot(want_g.astype(np.float32).astype(np.float64), res)
         assert np.max(np.abs(g6[0] - want6)) <= TOL * max(np.dot(np.abs(want_g), np.abs(res)).max(), 1e-30), (case, v)
         assert not g6[1].any()

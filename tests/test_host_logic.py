@@ -56,7 +56,7 @@ def test_no_gpu_means_loud_failure(built_lib):
 
 def test_geometry_check_guards_without_a_gpu(built_lib):
     """tomo_check_geometry (the validation inside tomo_set_geometry) runs on the host: bad shapes, the 2^31-voxel limit, and
-    the wide-row flag that keeps the 24-bit-multiply kernels away from slabs whose x-row pitch is >= 2^24 bytes."""
+    the wide-row flag that keeps the 24-bit-multiply kernels away from slabs whose x-row pitch is >= 2^23 bytes."""
     def check(shape, ndet=(8, 8), step=1.0):
         g = _lib.TomoGeom()
         g.nx, g.ny, g.nz = shape
@@ -66,13 +66,10 @@ def test_geometry_check_guards_without_a_gpu(built_lib):
         flags = ctypes.c_int(-1)
         return built_lib.tomo_check_geometry(ctypes.byref(g), ctypes.byref(flags)), flags.value
     assert check((64, 64, 64)) == (0, 0)
-    assert check((1024, 1024, 1024)) == (0, 0)                 # row pitch 1028 * 1028 * 4 = 4.2 MB < 2^24
-    assert check((16, 2044, 2048)) == (0, _lib.GEOM_WIDE_ROWS)  # 2048 * 2052 * 4 = 16 809 984 >= 2^24 = 16 777 216
-    rc, fl = check((16, 2045, 2045))                           # 2049 * 2049 * 4 = 16 793 604 >= 2^24 = 16 777 216
-    assert rc == 0 and fl == _lib.GEOM_WIDE_ROWS
-    rc, fl = check((16, 4096, 4096))
-    assert rc == 0 and fl == _lib.GEOM_WIDE_ROWS
-    assert check((16, 2040, 2040)) == (0, 0)                   # 2044 * 2044 * 4 = 16 711 744 < 2^24
+    assert check((1024, 1024, 1024)) == (0, 0)                 # row pitch 1028 * 1028 * 4 = 4.2 MB < 2^23
+    assert check((16, 1440, 1440)) == (0, 0)                   # 1444 * 1444 * 4 = 8 340 544 < 2^23 = 8 388 608
+    assert check((16, 1445, 1445)) == (0, _lib.GEOM_WIDE_ROWS)  # 1449 * 1449 * 4 = 8 398 404 >= 2^23
+    assert check((16, 4096, 4096)) == (0, _lib.GEOM_WIDE_ROWS)
     assert check((2048, 2048, 2048))[0] == -5                  # TOMO_ERR_UNSUPPORTED: padded volume >= 2^31 voxels
     assert check((0, 8, 8))[0] == -2 and check((8, 8, 8), step=0.0)[0] == -2
     assert check((2048, 2048, 2048))[0] == -5 and b"2^31" in built_lib.tomo_last_error(None)
@@ -306,3 +303,30 @@ def test_batched_alignment_recovers_injected_poses(shepp32):
     assert res["n_launch"] == int(res["nfev"].max())       # lock step: one launch per round
     res2 = alignment.align_projections_sharded(SingleComm(), be, shepp32, b, phi, letters="xzab", bounds=bounds)
     assert np.allclose(res2["x"], res["x"], atol=1e-9)
+
+
+def test_bench_launcher_and_roofline_logic_without_a_gpu(tmp_path, monkeypatch):
+    """bench.py on the CPU: (i) `--gpus 2` with no visible GPU fails cleanly before anything is started; (ii) the roofline picks
+    the busiest unit from committed counters and never reports the algorithmic-HBM figure as the fraction when counters exist."""
+    import json
+    import subprocess
+    import sys
+    import ctypes
+    n = ctypes.c_int(0)
+    if _lib.load().tomo_device_count(ctypes.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 2 and "2 GPUs requested, 0 visible" in out.stderr and out.stdout.strip() == ""
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    json.dump({"key": "K", "source": "t", "kernels": {"k_fwd_tile_flat": {"SQ_INSTS_VALU": 2.0e11, "SQ_INSTS_LDS": 6.0e10, "lds_bytes": 6.0e10 * 512}}}, open(prof / "sq_counters.json", "w"))
+    json.dump({"key": "K", "source": "t", "kernels": {"k_fwd_tile_flat": {"hbm_bytes_per_launch": 4.0e11}}}, open(prof / "pmc_traffic.json", "w"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    r = bench.make_roofline("k_fwd_tile_flat", 500.0, 1.0, 4.4e12, "K")
+    assert r["bound"] == "lds" and r["unit"] == "GB/s" and 0.0 < r["frac"] <= 1.0
+    assert abs(r["frac"] - 6.0e10 * 512 / 0.5 / 1e9 / bench.LDS_PEAK_GBS) < 1e-3
+    assert r["utilisation"]["valu_issue"]["frac"] < r["frac"] and r["utilisation"]["hbm"]["frac"] < 0.2
+    assert r["hbm_algorithmic"]["frac_of_hbm_peak"] > 1.0 and r["traffic"] == 4.0e11          # kept, labelled, not the roofline
+    r2 = bench.make_roofline("k_fwd_tile_flat", 500.0, 1.0, 4.4e12, "other-workload")
+    assert r2["bound"] == "hbm" and r2["counters"] is None and "no committed PMC counters" in r2["note"]

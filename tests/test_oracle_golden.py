@@ -164,3 +164,30 @@ def test_sirt_sensitivity_to_operator_rounding():
         print("SIRT x10 (positivity=%s): iterate moves by %.1f x eps (rel-max), %.1f x eps (rel-L2); rms_error by %.2f x eps"
               % (positivity, a_max, a_l2, np.max(np.abs(err - err0) / err0) / eps))
         assert 1.0 < a_max < 10.0 and a_l2 < 5.0
+
+
+def test_regularized_vector_kernels_vs_reference_golden():
+    """G9: recon/regularized.py:433 soft_thresholding, utilities/tv_denoise.py tv_norm_3d / denoise_fista (3-D) -- the oracle's
+    restatements are bit-identical to the reference's outputs (same numpy float32 operations in the same order)."""
+    g = golden("g9_regularized")
+    assert np.array_equal(orc.soft_thresholding(g["st_x"], np.float32(g["st_lambda"])), g["st_out"])
+    assert np.isclose(orc.tv_norm_3d(g["tv_im"]), float(g["tv_norm"]), rtol=1e-7)
+    cases = {"a": dict(weight=0.2, niter=20, eps=0.0, check_gap_frequency=3), "b": dict(weight=0.05, niter=200, eps=1.e-3, check_gap_frequency=3),
+             "c": dict(weight=0.5, niter=1, eps=0.0, check_gap_frequency=1), "d": dict(weight=0.5, niter=0)}
+    iters = {}
+    for tag, kw in cases.items():
+        out, iters[tag], _ = orc.tv_denoise_fista(g["tv_im"], return_info=True, **kw)
+        assert np.array_equal(out, g["tv_" + tag]), tag
+    assert iters == {"a": 20, "b": 6, "c": 1, "d": 0}          # b: the dual-gap stop fires at the third check
+    # tv_div is minus the adjoint of tv_gradient
+    rng = np.random.default_rng(0)
+    u, v = rng.standard_normal((5, 6, 7)), rng.standard_normal((3, 5, 6, 7))
+    vm = v * _last_zero((5, 6, 7))
+    assert np.isclose(np.sum(orc.tv_gradient(u) * vm), -np.sum(u * orc.tv_div(vm)), rtol=1e-10)
+
+
+def _last_zero(shape):
+    """mask that zeroes each component at its own axis' last index (the range of tv_gradient)"""
+    m = np.ones((3,) + shape)
+    m[0][-1], m[1][:, -1], m[2][:, :, -1] = 0, 0, 0
+    return m

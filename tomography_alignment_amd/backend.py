@@ -195,5 +195,24 @@ class HipBackend(object):
         self.ctx.check(self.lib.tomo_vec_diff_sumsq(self.ctx.handle, a.ptr, b.ptr, a.size, ctypes.byref(s)))
         return s.value
 
+    # ---- regularised solvers' vector kernels (recon/regularized.py:433, utilities/tv_denoise.py:98-170)
+    def soft_threshold(self, out, x, lam):
+        self.ctx.check(self.lib.tomo_vec_soft_threshold(self.ctx.handle, out.ptr, x.ptr, x.size, float(lam)))
+        return out
+
+    def tv_denoise_fista(self, im, out, shape, weight=50, niter=200, eps=1.e-5, check_gap_frequency=3):
+        """-> (iterations done, last dual gap); `out` holds the reference's return value."""
+        nx, ny, nz = (int(v) for v in shape)
+        it, gap = ctypes.c_int(0), ctypes.c_double(0)
+        self.ctx.check(self.lib.tomo_tv_denoise_fista(self.ctx.handle, im.ptr, out.ptr, nx, ny, nz, float(weight), int(niter), float(eps),
+                                                      int(check_gap_frequency), ctypes.byref(it), ctypes.byref(gap)))
+        return it.value, gap.value
+
+    def tv_norm_3d(self, x, shape):
+        nx, ny, nz = (int(v) for v in shape)
+        v = ctypes.c_double(0)
+        self.ctx.check(self.lib.tomo_tv_norm_3d(self.ctx.handle, x.ptr, nx, ny, nz, ctypes.byref(v)))
+        return v.value
+
     def sync(self):
         self.ctx.sync()

@@ -3,14 +3,20 @@ Multi-GPU communicator: RCCL over xGMI through the C-ABI (tomo_comm_* / tomo_all
 per GPU.  Replaces the mpi4py COMM_WORLD object the reference's recon/*_mpi.py take as first argument
 (recon/sirt_mpi.py:12,38-39: Get_size / Get_rank; :68,103 Allreduce(SUM); :110 scalar allreduce).
 
-Bootstrap: rank 0 creates the ncclUniqueId and publishes it through a file keyed by the launcher
-(MASTER_PORT + the launcher's pid); the other ranks of the node poll for it.  Launch contract:
-`python -m torch.distributed.run --nproc-per-node N ...` exports RANK / LOCAL_RANK / WORLD_SIZE; this
-module only reads those variables -- it does not import torch.
+Bootstrap: rank 0 creates the ncclUniqueId and serves it over a loopback TCP socket next to the launcher's
+MASTER_PORT; the other ranks of the node connect and fetch it.  Every exchange carries the launch key (the
+launcher's port, run id and pid, or the nonce bench.py's own launcher exports), so a rank can only ever
+receive the id of ITS launch: a listener left behind by a crashed earlier launch answers "not yours" and the
+rank moves on to the next candidate port.  (An earlier version passed the id through a file in /tmp, which a
+crashed launch with the same key could leave behind for the next one to read.)  Launch contract:
+`python -m torch.distributed.run --nproc-per-node N ...` -- or `python bench.py --gpus N`, which spawns the
+ranks itself -- exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT; this module only reads those variables,
+it does not import torch.
 """
 import ctypes
 import os
-import tempfile
+import socket
+import struct
 import time
 
 import numpy as np
@@ -20,32 +26,104 @@ try:
 except ImportError:      # package directory itself on sys.path
     import _lib
 
+N_CANDIDATE_PORTS = 8
+
 
 def rendezvous_key():
-    """Identifies one launch: the launcher's port and run id plus its pid (all ranks of a node share the parent)."""
+    """Identifies one launch: an explicit nonce (TOMO_RDV_KEY, set by bench.py's launcher) or the launcher's port and run id
+    plus its pid (all ranks of a node share the parent)."""
+    k = os.environ.get("TOMO_RDV_KEY")
+    if k:
+        return k
     return "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
 
 
-def exchange_from_rank0(rank, size, make_payload, timeout=300.0, directory=None, key=None):
-    """Rank 0 calls make_payload() and publishes the bytes through a file; every other rank polls for it and reads
-    it.  The file is written atomically (tmp + rename) and left for the ranks to read; stale files of earlier launches
-    cannot collide because the key carries the launcher's pid.  Returns the payload on every rank."""
-    directory = directory or tempfile.gettempdir()
-    path = os.path.join(directory, "tomo_rccl_%s.id" % (key or rendezvous_key()))
+def candidate_ports(base=None):
+    """Loopback ports the id server may sit on: TOMO_RDV_PORT or MASTER_PORT + 1, and the next few (first free wins)."""
+    if base is None:
+        base = int(os.environ.get("TOMO_RDV_PORT") or (int(os.environ.get("MASTER_PORT", "29500")) + 1))
+    return [1024 + (int(base) + i - 1024) % (65536 - 1024) for i in range(N_CANDIDATE_PORTS)]
+
+
+def _recv_exact(sock, n):
+    buf = b""
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("peer closed")
+        buf += chunk
+    return buf
+
+
+def exchange_from_rank0(rank, size, make_payload, timeout=300.0, key=None, port=None):
+    """Rank 0 calls make_payload() and serves the bytes on 127.0.0.1 until the size - 1 other ranks of THIS launch (same
+    key) have fetched them; every other rank connects (retrying until `timeout`) and returns them.  Returns the payload on
+    every rank."""
+    key_b = (key or rendezvous_key()).encode()
+    ports = candidate_ports(port)
     if rank == 0:
         payload = make_payload()
-        tmp = path + ".tmp%d" % os.getpid()
-        with open(tmp, "wb") as f:
-            f.write(payload)
-        os.replace(tmp, path)
+        if size <= 1:
+            return payload
+        srv = None
+        for p in ports:
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            try:
+                s.bind(("127.0.0.1", p))
+                s.listen(64)
+                srv = s
+                break
+            except OSError:
+                s.close()
+        if srv is None:
+            raise _lib.TomoError("RCCL id rendezvous: none of the loopback ports %s is free" % ports)
+        served, deadline = 0, time.time() + timeout
+        try:
+            while served < size - 1:
+                srv.settimeout(max(0.05, deadline - time.time()))
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    raise _lib.TomoError("RCCL id rendezvous: %d of %d ranks fetched the id within %.0f s" % (served, size - 1, timeout))
+                try:
+                    conn.settimeout(5.0)
+                    n = struct.unpack("<I", _recv_exact(conn, 4))[0]
+                    theirs = _recv_exact(conn, n) if n < 4096 else b""
+                    if theirs == key_b:
+                        conn.sendall(b"OK" + struct.pack("<I", len(payload)) + payload)
+                        _recv_exact(conn, 1)               # the rank confirms it holds the bytes
+                        served += 1
+                    else:
+                        conn.sendall(b"NO")                # somebody else's launch
+                except (OSError, ConnectionError, struct.error):
+                    pass
+                finally:
+                    conn.close()
+        finally:
+            srv.close()
         return payload
-    t0 = time.time()
-    while not os.path.exists(path):
-        if time.time() - t0 > timeout:
-            raise _lib.TomoError("timed out waiting for the RCCL id file %s" % path)
-        time.sleep(0.02)
-    with open(path, "rb") as f:
-        return f.read()
+    deadline = time.time() + timeout
+    while True:
+        for p in ports:
+            try:
+                c = socket.create_connection(("127.0.0.1", p), timeout=1.0)
+            except OSError:
+                continue
+            try:
+                c.settimeout(10.0)
+                c.sendall(struct.pack("<I", len(key_b)) + key_b)
+                if _recv_exact(c, 2) == b"OK":
+                    n = struct.unpack("<I", _recv_exact(c, 4))[0]
+                    payload = _recv_exact(c, n)
+                    c.sendall(b"!")
+                    return payload
+            except (OSError, ConnectionError, struct.error):
+                pass
+            finally:
+                c.close()
+        if time.time() > deadline:
+            raise _lib.TomoError("timed out waiting for rank 0's RCCL id on 127.0.0.1 ports %s (key %s)" % (ports, key_b.decode()))
+        time.sleep(0.05)
 
 
 class SingleComm(object):
@@ -114,12 +192,7 @@ class RcclComm(object):
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         uid = exchange_from_rank0(rank, size, lambda: cls.unique_id(ctx.lib), timeout=timeout)
         comm = cls(ctx, rank, size, uid)
-        comm.barrier()                  # every rank has joined the communicator, hence has read the id
-        if rank == 0:
-            try:
-                os.remove(os.path.join(tempfile.gettempdir(), "tomo_rccl_%s.id" % rendezvous_key()))
-            except OSError:
-                pass
+        comm.barrier()                  # every rank has joined the communicator
         return comm
 
     def allreduce_sum_(self, buf):

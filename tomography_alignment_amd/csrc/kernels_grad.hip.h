@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
     const int J0 = __builtin_amdgcn_readfirstlane(wave_min_i32(nonempty ? r.j0 : INT_MAX));
     const int J1 = __builtin_amdgcn_readfirstlane(wave_max_i32(nonempty ? r.j1 : 0));
     const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
-    const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;
+    const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;     // < 2^23 (tomo_check_geometry): signed 24-bit multiplies
+    const uint32_t abias4 = tomo_abias_bytes(sx4, sy4);
     const float sfs = (float)(g.step / c.rlen);
     // Eight DWORD gathers per sample, on purpose: with lanes on consecutive z cells a wave-wide global_load_dword costs
     // 4.8 cycles of the CU's texture-address/L1 pipeline, a dwordx2 (or x4) 17 (tools/gather_bench.hip), and that pipeline
@@ -177,12 +178,12 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
         const int64_t lin0 = readfirstlane_i64(lin);
         const int delta = (int)(lin - lin0);
         const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(delta));
-        const char *sb00 = (const char *)(vp + (lin0 + m));
+        const char *sb00 = (const char *)(vp + (lin0 + m)) - abias4;      // cells relative to the anchor are signed: see tomo_block_anchor
         const char *sb01 = sb00 + sy4;
         const char *sb10 = sb00 + sx4;
         const char *sb11 = sb10 + sy4;
         const char *sc00 = sb00 + four, *sc01 = sb01 + four, *sc10 = sb10 + four, *sc11 = sb11 + four;   // the z + 1 corners
-        const uint32_t off0 = (uint32_t)(delta - m) * 4u;
+        const uint32_t off0 = (uint32_t)(delta - m) * 4u + abias4;
         const int lo = max(r.j0, jb) - jb, hi = min(r.j1, jb + TOMO_JB) - jb;      // this lane's samples of the block
         float av = 0.f;
         f32x2 a0xy = {0.f, 0.f}, a1xy = {0.f, 0.f}, az = {0.f, 0.f};              // (S0x, S0y), (S1x, S1y), (S0z, S1z)
@@ -196,8 +197,8 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
             const float xb = fmaf(tb, dxf, f0[0]), yb = fmaf(tb, dyf, f0[1]), zb = fmaf(tb, dzf, f0[2]);
             const float fxa = floorf(xa), fya = floorf(ya), fza = floorf(za);
             const float fxb = floorf(xb), fyb = floorf(yb), fzb = floorf(zb);
-            const uint32_t voa = off0 + __umul24((uint32_t)(int)fxa, sx4) + __umul24((uint32_t)(int)fya, sy4) + ((uint32_t)(int)fza << 2);
-            const uint32_t vob_ = off0 + __umul24((uint32_t)(int)fxb, sx4) + __umul24((uint32_t)(int)fyb, sy4) + ((uint32_t)(int)fzb << 2);
+            const uint32_t voa = off0 + (uint32_t)__mul24((int)fxa, (int)sx4) + (uint32_t)__mul24((int)fya, (int)sy4) + ((uint32_t)(int)fza << 2);
+            const uint32_t vob_ = off0 + (uint32_t)__mul24((int)fxb, (int)sx4) + (uint32_t)__mul24((int)fyb, (int)sy4) + ((uint32_t)(int)fzb << 2);
             const uint32_t vob = two ? vob_ : voa;
             const f32x2 a00 = {*(const float *)(sb00 + voa), *(const float *)(sc00 + voa)};
             const f32x2 a01 = {*(const float *)(sb01 + voa), *(const float *)(sc01 + voa)};
@@ -344,7 +345,8 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
     const int J0 = __builtin_amdgcn_readfirstlane(wave_min_i32(nonempty ? r.j0 : INT_MAX));
     const int J1 = __builtin_amdgcn_readfirstlane(wave_max_i32(nonempty ? r.j1 : 0));
     const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
-    const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;
+    const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;     // < 2^23 (tomo_check_geometry): signed 24-bit multiplies
+    const uint32_t abias4 = tomo_abias_bytes(sx4, sy4);
     const float sfs = (float)(g.step / c.rlen);
     double val = 0.0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
     for (int jb = J0; jb < J1; jb += TOMO_JB) {
@@ -355,11 +357,11 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
         const int64_t lin0 = readfirstlane_i64(lin);
         const int delta = (int)(lin - lin0);
         const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(delta));
-        const char *sb00 = (const char *)(vp + (lin0 + m));
+        const char *sb00 = (const char *)(vp + (lin0 + m)) - abias4;      // cells relative to the anchor are signed: see tomo_block_anchor
         const char *sb01 = sb00 + sy4;
         const char *sb10 = sb00 + sx4;
         const char *sb11 = sb10 + sy4;
-        const uint32_t off0 = (uint32_t)(delta - m) * 4u;
+        const uint32_t off0 = (uint32_t)(delta - m) * 4u + abias4;
         const int lo = max(r.j0, jb) - jb, hi = min(r.j1, jb + TOMO_JB) - jb;      // this lane's samples of the block
         const bool has = hi > lo;
         const unsigned long long hm = __ballot(has);
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
         {
             const float t = (float)lo;
             const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
-            const uint32_t mine = off0 + __umul24((uint32_t)(int)floorf(x), sx4) + __umul24((uint32_t)(int)floorf(y), sy4) + ((uint32_t)(int)floorf(z) << 2);
+            const uint32_t mine = off0 + (uint32_t)__mul24((int)floorf(x), (int)sx4) + (uint32_t)__mul24((int)floorf(y), (int)sy4) + ((uint32_t)(int)floorf(z) << 2);
             borrow = (uint32_t)__builtin_amdgcn_readlane((int)mine, __builtin_ctzll(hm));
         }
         const int lo_c = has ? lo : 0, hi_c = has ? hi - 1 : 0;
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
         const float x = fmaf(S##t, dxf, f0[0]), y = fmaf(S##t, dyf, f0[1]), z = fmaf(S##t, dzf, f0[2]);                            \
         const float fx = floorf(x), fy = floorf(y), fz = floorf(z);                                                                \
         S##wx = x - fx; S##wy = y - fy; S##wz = z - fz;                                                                            \
-        const uint32_t vo_own = off0 + __umul24((uint32_t)(int)fx, sx4) + __umul24((uint32_t)(int)fy, sy4) + ((uint32_t)(int)fz << 2); \
+        const uint32_t vo_own = off0 + (uint32_t)__mul24((int)fx, (int)sx4) + (uint32_t)__mul24((int)fy, (int)sy4) + ((uint32_t)(int)fz << 2); \
         const uint32_t vo = has ? vo_own : borrow;                                                                                 \
         S##v000 = *(const float *)(sb00 + vo); S##v010 = *(const float *)(sb01 + vo);                                              \
         S##v100 = *(const float *)(sb10 + vo); S##v110 = *(const float *)(sb11 + vo);                                              \

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void k_fwd_v2(const ProjC *__restrict__ pcs, c
     const int J0 = __builtin_amdgcn_readfirstlane(wave_min_i32(nonempty ? r.j0 : INT_MAX));
     const int J1 = __builtin_amdgcn_readfirstlane(wave_max_i32(nonempty ? r.j1 : 0));
     const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
-    const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;
+    const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;     // < 2^23 (tomo_check_geometry): signed 24-bit multiplies
+    const uint32_t abias4 = tomo_abias_bytes(sx4, sy4);
     // dword gathers on purpose (a wave-wide dwordx2 costs 3.5x a dword in the L1 pipeline, tools/gather_bench.hip): the z + 1
     // bases carry an offset the compiler cannot see through, so it does not fuse the corner pairs
     int four;
@@ -171,19 +172,20 @@ __global__ __launch_bounds__(256) void k_fwd_v2(const ProjC *__restrict__ pcs, c
         const int64_t lin0 = readfirstlane_i64(lin);
         const int delta = (int)(lin - lin0);       // neighbouring rays at the same j: a few rows apart
         const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(delta));
-        const char *sb00 = (const char *)(vp + (lin0 + m));
+        // cells relative to the (middle-of-block) anchor are signed: base lowered, lane offset raised by TOMO_ABIAS cells per axis
+        const char *sb00 = (const char *)(vp + (lin0 + m)) - abias4;
         const char *sb01 = sb00 + sy4;
         const char *sb10 = sb00 + sx4;
         const char *sb11 = sb10 + sy4;
         const char *sc00 = sb00 + four, *sc01 = sb01 + four, *sc10 = sb10 + four, *sc11 = sb11 + four;
-        const uint32_t off0 = (uint32_t)(delta - m) * 4u;
+        const uint32_t off0 = (uint32_t)(delta - m) * 4u + abias4;
         const int lo = max(r.j0, jb) - jb, hi = min(r.j1, jb + TOMO_JB) - jb;
         float acc = 0.f;
         for (int jj = lo; jj < hi; ++jj) {
             const float t = (float)jj;
             const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
             const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-            const uint32_t vo = off0 + __umul24((uint32_t)(int)fx, sx4) + __umul24((uint32_t)(int)fy, sy4) + ((uint32_t)(int)fz << 2);
+            const uint32_t vo = off0 + (uint32_t)__mul24((int)fx, (int)sx4) + (uint32_t)__mul24((int)fy, (int)sy4) + ((uint32_t)(int)fz << 2);
             const float v000 = *(const float *)(sb00 + vo), v001 = *(const float *)(sc00 + vo);
             const float v010 = *(const float *)(sb01 + vo), v011 = *(const float *)(sc01 + vo);
             const float v100 = *(const float *)(sb10 + vo), v101 = *(const float *)(sc10 + vo);

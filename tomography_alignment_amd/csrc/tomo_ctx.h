@@ -77,6 +77,8 @@ int tomo_ensure_stage(tomo_ctx *ctx, size_t bytes);
 int tomo_ensure_red(tomo_ctx *ctx, size_t n_doubles);
 void tomo_prof_begin(tomo_ctx *ctx, const char *name);
 void tomo_prof_end(tomo_ctx *ctx);
+void tomo_prof_begin_on(tomo_ctx *ctx, const char *name, hipStream_t stream);
+void tomo_prof_end_on(tomo_ctx *ctx, hipStream_t stream);
 
 #define TOMO_HIP(ctx, call)                                                                         \
     do {                                                                                            \

@@ -186,8 +186,8 @@ extern "C" int tomo_check_geometry(const tomo_geom *g, int *flags)
         return tomo_fail(nullptr, TOMO_ERR_ARG, "set_geometry: non-positive shape/step or det_y <= src_y");
     const size_t nxp = (size_t)g->nx + 2 * TOMO_HALO, nyp = (size_t)g->ny + 2 * TOMO_HALO, nzp = (size_t)g->nz + 2 * TOMO_HALO;
     if (nxp * nyp * nzp >= ((size_t)1 << 31)) return tomo_fail(nullptr, TOMO_ERR_UNSUPPORTED, "set_geometry: padded volume exceeds 2^31 voxels");
-    // the SGPR-base kernels (k_fwd_v2, k_proj_grad_v2/_v3) form lane offsets with 24-bit multiplies: cell * (row pitch in bytes)
-    if (nyp * nzp * 4 >= ((size_t)1 << 24) || nzp * 4 >= ((size_t)1 << 24)) { if (flags) *flags |= TOMO_GEOM_WIDE_ROWS; }
+    // the SGPR-base kernels (k_fwd_v2, k_proj_grad_v2/_v3) form lane offsets with SIGNED 24-bit multiplies: cell * (row pitch in bytes)
+    if (nyp * nzp * 4 >= ((size_t)1 << 23) || nzp * 4 >= ((size_t)1 << 23)) { if (flags) *flags |= TOMO_GEOM_WIDE_ROWS; }
     return TOMO_OK;
 }
 
@@ -234,27 +234,31 @@ static hipEvent_t prof_event(tomo_ctx *ctx)
     return e;
 }
 
-void tomo_prof_begin(tomo_ctx *ctx, const char *name)
+void tomo_prof_begin_on(tomo_ctx *ctx, const char *name, hipStream_t stream)
 {
     if (!ctx->profile_on) return;
     ProfPending p;
     p.name = name;
     p.e0 = prof_event(ctx);
     p.e1 = prof_event(ctx);
-    (void)hipEventRecord(p.e0, ctx->stream);
+    (void)hipEventRecord(p.e0, stream);
     ctx->pending.push_back(p);
 }
 
-void tomo_prof_end(tomo_ctx *ctx)
+void tomo_prof_end_on(tomo_ctx *ctx, hipStream_t stream)
 {
     if (!ctx->profile_on || ctx->pending.empty()) return;
-    (void)hipEventRecord(ctx->pending.back().e1, ctx->stream);
+    (void)hipEventRecord(ctx->pending.back().e1, stream);
 }
+
+void tomo_prof_begin(tomo_ctx *ctx, const char *name) { tomo_prof_begin_on(ctx, name, ctx->stream); }
+void tomo_prof_end(tomo_ctx *ctx) { tomo_prof_end_on(ctx, ctx->stream); }
 
 static void prof_drain(tomo_ctx *ctx)
 {
     if (ctx->pending.empty()) return;
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);     // asynchronous all-reduces are bracketed on their own stream
     for (auto &p : ctx->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
@@ -615,7 +619,11 @@ extern "C" int tomo_allreduce_sum_f32_async(tomo_ctx *ctx, float *d_buf, int64_t
     }
     TOMO_HIP(ctx, hipEventRecord(ctx->ev_compute, ctx->stream));
     TOMO_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_compute, 0));
+    // profile record "allreduce_f32": on the communication stream, so it holds the collective's own duration (peers' arrival
+    // skew included) whether or not the compute stream ever waits for it -- "comm_join_wait" below is the exposed part
+    tomo_prof_begin_on(ctx, "allreduce_f32", ctx->comm_stream);
     ncclResult_t r = ncclAllReduce(d_buf, d_buf, (size_t)n, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream);
+    tomo_prof_end_on(ctx, ctx->comm_stream);
     if (r != ncclSuccess) return tomo_fail(ctx, TOMO_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
     TOMO_HIP(ctx, hipEventRecord(ctx->ev_comm, ctx->comm_stream));
     ctx->comm_pending = true;
@@ -626,7 +634,11 @@ extern "C" int tomo_comm_join(tomo_ctx *ctx)
 {
     if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
     if (ctx->comm_pending) {
+        // "comm_join_wait": time the compute stream sits between the end of its own work and the end of the last asynchronous
+        // all-reduce = the communication the pipeline failed to hide
+        tomo_prof_begin(ctx, "comm_join_wait");
         TOMO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_comm, 0));   // events on one stream complete in order: the last covers all
+        tomo_prof_end(ctx);
         ctx->comm_pending = false;
     }
     return TOMO_OK;

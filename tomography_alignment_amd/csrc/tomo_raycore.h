@@ -12,8 +12,8 @@
 // temporaries.  Volumes are read through a zero halo of TOMO_HALO voxels, which turns the
 // per-corner bounds tests into plain loads of zeros (identical result: an out-of-bounds corner
 // contributes 0).  Sample positions inside a block of TOMO_JB samples are float32 offsets from a
-// float64 integer anchor, so coordinates keep ~4e-6 voxel accuracy at 1024^3 where plain float32
-// (ulp 6e-5 at 1024) would not.
+// float64 integer anchor at the block's middle, so coordinates keep ~1e-6 voxel accuracy at 1024^3 where
+// plain float32 (ulp 6e-5 at 1024) would not.
 #ifndef TOMO_RAYCORE_H_
 #define TOMO_RAYCORE_H_
 #include <math.h>
@@ -26,8 +26,7 @@
 #endif
 
 #define TOMO_HALO 2   // zero voxels on every side of the padded volume
-#define TOMO_JB 32    // samples per re-anchored block in the ray-driven kernels (in-block offsets < 35: ulp 3.8e-6 voxel)
-#define TOMO_TILE_JB 64  // ... in the tile kernels (rows are short: fewer anchors; offsets < 67: ulp 7.6e-6 voxel)
+#define TOMO_JB 32    // samples per re-anchored block in the ray-driven kernels (in-block coordinates within +-17 of the anchor)
 
 struct TomoGeomC {    // device-side copy of tomo_geom
     int32_t nx, ny, nz, ndx, ndz;
@@ -155,18 +154,23 @@ TOMO_HD void tomo_ray_range(const double b[3], const double d[3], int n, int nx,
     if (j1 < j0) j1 = j0;
 }
 
-// Block anchor: one below the integer floor of the smallest coordinate the block [jb, jb+TOMO_JB)
-// reaches, so in-block offsets are >= 1 (their floors stay >= 0 under float32 rounding, which the
-// unsigned 24-bit offset arithmetic of the kernels relies on) and < TOMO_JB*|d|+3.
+// Block anchor: the integer floor of the block's MIDDLE position, so the float32 in-block coordinates x = f0 + jj*d stay within
+// +-(TOMO_JB/2 * |d| + 1) <= +-17: float32 rounding of a sample position <= ~1e-6 voxel (f0 and the fma each round at
+// ulp(16) = 1.9e-6 at the block ends, 2.4e-7 in the middle) -- half of what an anchor below the block's lowest corner gave
+// (coordinates up to 35), which at 512^3 left the pose gradient only just inside 1e-5 of the float64 reference on a
+// piecewise-constant phantom (tests/test_gpu_configs.py).  Cells relative to the anchor lie in [-TOMO_ABIAS + 1, TOMO_ABIAS - 1]:
+// the kernels that form UNSIGNED 32-bit byte offsets lower their wave-uniform base pointer by TOMO_ABIAS cells per axis and
+// add the same to the lane offset (tomo_abias_bytes).
+#define TOMO_ABIAS 18
 TOMO_HD void tomo_block_anchor(const double b[3], const double d[3], int jb, int ia[3], float f0[3], int span = TOMO_JB)
 {
     for (int a = 0; a < 3; ++a) {
         double s = b[a] + (double)jb * d[a];
-        double e = s + (double)(span - 1) * d[a];
-        double f = floor(s < e ? s : e) - 1.0;
+        double f = floor(s + 0.5 * (double)(span - 1) * d[a]);
         ia[a] = (int)f;
         f0[a] = (float)(s - f);
     }
 }
+TOMO_HD uint32_t tomo_abias_bytes(uint32_t sx4, uint32_t sy4) { return (uint32_t)TOMO_ABIAS * (sx4 + sy4 + 4u); }
 
 #endif  // TOMO_RAYCORE_H_

@@ -29,13 +29,18 @@ def find(d, pat):
 
 
 def pmc(d, name):
+    """kernel -> per-dispatch totals of counter `name`, in dispatch order"""
     out = {}
     if not d:
         return out
     path = find(d, "*counter_collection.csv")
+    per = {}
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == name:
-            out.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
+            k = (short(r["Kernel_Name"]), int(r["Dispatch_Id"]))
+            per[k] = per.get(k, 0.0) + float(r["Counter_Value"])
+    for (k, i) in sorted(per, key=lambda t: t[1]):
+        out.setdefault(k, []).append(per[(k, i)])
     return out
 
 
@@ -48,6 +53,8 @@ def main():
     ap.add_argument("--workload", default="")
     ap.add_argument("--out", default="profiles")
     ap.add_argument("--key", default="", help="workload key bench.py matches, e.g. N1024_A1024_G1")
+    ap.add_argument("--which", default="max", choices=["max", "last"],
+                    help="which dispatch of a kernel the PMC table reports: the largest, or the last (= the timed step of a --steps 1 --warmup 1 run)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     rows = list(csv.DictReader(open(find(a.stats_dir, "*kernel_stats.csv"))))
@@ -71,11 +78,12 @@ def main():
                 lines.append("* `%s`: %s" % (k, ", ".join("%.1f" % x for x in v)))
     traffic = {}
     if fetch or write:
-        lines += ["", "## PMC passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, separate runs; per launch, max over launches)", "",
+        pick = (lambda v: v[-1]) if a.which == "last" else max
+        lines += ["", "## PMC passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, separate runs; per launch, %s dispatch of each kernel)" % a.which, "",
                   "| kernel | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes/launch = (2*F + W)*1024 |", "|---|---|---|---|"]
         for k in sorted(set(fetch) | set(write)):
-            f = max(fetch.get(k, [0.0]))
-            w = max(write.get(k, [0.0]))
+            f = pick(fetch.get(k, [0.0]))
+            w = pick(write.get(k, [0.0]))
             b = (2.0 * f + w) * 1024.0
             if b < 1e6:
                 continue
