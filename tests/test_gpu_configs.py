@@ -123,16 +123,23 @@ def test_config5_projection_gradient_512_all_variants(c5, capsys):
             per_variant[v, k] = (p, g)
             ok = fd > 2e-5
             e_p = rel_max(p, p0)
-            e_g = max(float(np.max(np.abs(g[r][ok] - g0[r][ok])) / np.max(np.abs(g0[r]))) for r in range(6))
-            e_g_all = max(float(np.max(np.abs(g[r] - g0[r])) / np.max(np.abs(g0[r]))) for r in range(6))
-            rows.append((v, k, e_p, e_g, e_g_all, 1.0 - ok.mean()))
+            # rows of one unit are measured against the largest of them (translations tx, ty, tz; angles phi, alpha, beta): the
+            # translation along the beam telescopes to ~0 along a ray (f(exit) - f(entry)), so its own maximum is no yardstick
+            # for the rounding of a 500-term sum -- the convention of test_cost_grad_cache_ordered_grid_vs_oracle
+            unit = [max(np.max(np.abs(g0[r])) for r in grp) for grp in ((0, 1, 2), (3, 4, 5)) for _ in grp]
+            per_row = [float(np.max(np.abs(g[r][ok] - g0[r][ok])) / unit[r]) for r in range(6)]
+            own_row = [float(np.max(np.abs(g[r][ok] - g0[r][ok])) / np.max(np.abs(g0[r]))) for r in range(6)]
+            e_g = max(per_row)
+            e_g_all = max(float(np.max(np.abs(g[r] - g0[r])) / unit[r]) for r in range(6))
+            rows.append((v, k, e_p, e_g, e_g_all, 1.0 - ok.mean(), own_row))
     be.ctx.set_option("grad_variant", 4)
     with capsys.disabled():
         print("\n[C5 512^3] oracle (3 poses, %d threads): %.0f s" % (_threads(), c5["t_oracle"]))
-        for v, k, e_p, e_g, e_g_all, frac in rows:
+        for v, k, e_p, e_g, e_g_all, frac, own in rows:
             print("[C5 512^3] grad_variant %d pose %d: proj rel-max %.2e | grad rel-max %.2e on well-conditioned rays (%.1f %% of rays "
-                  "within 2e-5 voxel of a cell face excluded; all rays: %.2e)" % (v, c5["pick"][k], e_p, e_g, 100 * frac, e_g_all))
-    for v, k, e_p, e_g, e_g_all, frac in rows:
+                  "within 2e-5 voxel of a cell face excluded; all rays: %.2e) | each row against its own max: %s"
+                  % (v, c5["pick"][k], e_p, e_g, 100 * frac, e_g_all, " ".join("%.1e" % x for x in own)))
+    for v, k, e_p, e_g, e_g_all, frac, own in rows:
         assert e_p < TOL and e_g < TOL and frac < 0.10, (v, k, e_p, e_g, frac)
     # variants 2-4 walk the same wave-uniform sample blocks (same float32 positions, same cell for every sample): identical sums
     # on every ray; variant 1 anchors its blocks per ray, so a sample ON a cell face may fall on the other side -- compared on

@@ -467,6 +467,52 @@ def test_gradient_kernels_idle_lane_addressing(PM, orc, case):
         assert not g6[1].any()
 
 
+@pytest.mark.parametrize("case", ["box", "single_voxel", "corner_voxels", "all_zero", "nan"])
+def test_rays_are_clipped_to_the_nonzero_box(PM, orc, case):
+    """The ray-driven kernels (forward variants 1 / 2, every gradient variant) walk a ray only where it can see a non-zero voxel
+    (box found while the volume is staged): same numbers as the oracle, which walks the whole volume."""
+    shape, ndet = (40, 36, 70), (44, 80)
+    rng = np.random.default_rng(77)
+    x = np.zeros(shape, np.float32)
+    if case == "box":
+        x[12:21, 5:30, 33:61] = rng.uniform(0.1, 1, (9, 25, 28))
+    elif case == "single_voxel":
+        x[17, 20, 3] = 2.0
+    elif case == "corner_voxels":
+        x[0, 0, 0] = 1.0
+        x[-1, -1, -1] = 3.0
+    elif case == "nan":
+        x[10:14, 10:14, 10:14] = 1.0
+        x[30, 30, 60] = np.nan                           # NaN is "non-zero": rays through it must come out NaN, as in the reference
+    geo, og = geo_pair(2, None, ndet=ndet, shape=shape)
+    phi, alpha, beta = np.array([0.5, 2.1]), np.deg2rad([1.5, -2.5]), np.deg2rad([-1.0, 2.0])
+    xyz = np.array([[1.5, 0.3, -2.0], [-2.5, 0.0, 3.0]])
+    want = orc.forward(og, x, alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz)
+    for fv in (1, 2):
+        P = PM(geo)
+        P.backend.ctx.set_option("fwd_variant", fv)
+        got = P.projection_matrix(alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz).dot(x.ravel()).reshape(want.shape)
+        if case == "all_zero":
+            assert not got.any()
+        elif case == "nan":
+            assert np.array_equal(np.isnan(got), np.isnan(want)) and rel_max(got[~np.isnan(want)], want[~np.isnan(want)]) < TOL
+        else:
+            assert rel_max(got, want) < TOL, (case, fv)
+    if case == "nan":
+        return
+    wp, wg = orc.projection_gradient(og, x, alpha[0], beta[0], phi[0], xyz[0], np.zeros(3), precision=np.float64)
+    for v in (1, 2, 3):
+        P = PM(geo, precision=np.float64)
+        P.backend.ctx.set_option("grad_variant", v)
+        p, gr = P.projection_gradient(x, alpha[0], beta[0], phi[0], xyz[0], np.zeros(3))
+        if case == "all_zero":
+            assert not p.any() and not gr.any()
+            continue
+        assert rel_max(p, wp) < TOL, (case, v)
+        for k in range(6):
+            assert np.max(np.abs(gr[k] - wg[k])) <= TOL * np.max(np.abs(wg[3 * (k // 3):3 * (k // 3) + 3])), (case, v, k)
+
+
 @pytest.mark.parametrize("ndet", [(384, 340), (402, 350)])      # 96 ix groups (XCD swizzle) / 101 (plain)
 def test_cost_grad_cache_ordered_grid_vs_oracle(PM, orc, ndet):
     """Volumes whose padded copy exceeds the Infinity Cache make grad_variant 2 walk the grid detector-z-chunk slowest

@@ -70,6 +70,11 @@ def test_geometry_check_guards_without_a_gpu(built_lib):
     assert check((16, 1440, 1440)) == (0, 0)                   # 1444 * 1444 * 4 = 8 340 544 < 2^23 = 8 388 608
     assert check((16, 1445, 1445)) == (0, _lib.GEOM_WIDE_ROWS)  # 1449 * 1449 * 4 = 8 398 404 >= 2^23
     assert check((16, 4096, 4096)) == (0, _lib.GEOM_WIDE_ROWS)
+    g = _lib.TomoGeom()
+    g.nx = g.ny = g.nz = g.ndx = g.ndz = 32
+    g.src_y, g.det_y, g.step, g.det_dx, g.det_dz = -32.0, 32.0, 1.0, 1.0, 1.5      # detector-z pitch > 1 voxel: plain kernels too
+    fl = ctypes.c_int(0)
+    assert built_lib.tomo_check_geometry(ctypes.byref(g), ctypes.byref(fl)) == 0 and fl.value == _lib.GEOM_WIDE_ROWS
     assert check((2048, 2048, 2048))[0] == -5                  # TOMO_ERR_UNSUPPORTED: padded volume >= 2^31 voxels
     assert check((0, 8, 8))[0] == -2 and check((8, 8, 8), step=0.0)[0] == -2
     assert check((2048, 2048, 2048))[0] == -5 and b"2^31" in built_lib.tomo_last_error(None)

@@ -3,65 +3,18 @@
 // kernels_grad); not compiled on its own.
 
 // ------------------------------------------------------------------------------------------------
-// projection + 6-DoF pose gradient.  Per sample only the interpolant's spatial gradient is formed
-// (3 values); S0 = sum_j grad_j and S1 = sum_j sf_j*grad_j are accumulated and the per-ray 9x3 pose
-// Jacobian is applied once (same algebra as src/ray_wt_grad.f90:136-149, SURVEY appendix A).
-// FUSED: multiply by the residual and reduce to 7 numbers per projection.
+// Shared tail of the gradient kernels: the per-ray 9x3 pose Jacobian applied ONCE to the accumulated S0 = sum_j grad_j and
+// S1 = sum_j sf_j grad_j (utilities/ray_voxel_utilities.py:38-49; same algebra as src/ray_wt_grad.f90:136-149), then either the
+// plain outputs (proj[n_det], grad[6][n_det]; row_order 1 = the Fortran twin's tx,ty,tz,alpha,beta,phi,
+// src/external_forward_projection.f90:56-69) or, FUSED, the residual and the 7 reductions of
+// utilities/alignment_functions.py:23-37,124,146 (wave shuffles -> LDS -> one double atomic per work-group and sum).
+// Must be reached by every thread of the work-group (FUSED ends in a barrier).
 // ------------------------------------------------------------------------------------------------
 template <bool FUSED>
-__global__ __launch_bounds__(256) void k_proj_grad(const ProjC *__restrict__ pcs, const GradC *__restrict__ gcs,
-                                                   const float *__restrict__ vp, float *__restrict__ proj,
-                                                   float *__restrict__ grad, const float *__restrict__ bvec,
-                                                   float *__restrict__ resid, double *__restrict__ red, TomoGeomC g,
-                                                   int row_order)
+__device__ __forceinline__ void grad_finish(const GradC &gc, const TomoGeomC &g, int ixc, int iz, bool valid, double val, const double s0[3],
+                                            const double s1[3], float *__restrict__ proj, float *__restrict__ grad, const float *__restrict__ bvec,
+                                            float *__restrict__ resid, double *__restrict__ red, int row_order, int lane, int wv)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ix = blockIdx.y * 4 + wv, ip = blockIdx.z;
-    int iz = blockIdx.x * 64 + lane;
-    const bool valid = (ix < g.ndx) && (iz < g.ndz);
-    const int ixc = min(ix, g.ndx - 1);
-    if (iz >= g.ndz) iz = g.ndz - 1;
-    const ProjC &c = pcs[ip];
-    const GradC &gc = gcs[ip];
-    RayCtx r;
-    ray_setup(c, g, ixc, iz, valid, r);
-    const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
-    const int64_t sy = g.nzp, sx = (int64_t)g.nyp * g.nzp;
-    const float sfs = (float)(g.step / c.rlen);      // sf_j = (j*step)/|r_0|   ray_voxel_utilities.py:151
-    double val = 0.0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
-    for (int jb = r.j0; jb < r.j1; jb += TOMO_JB) {
-        int ia[3];
-        float f0[3];
-        tomo_block_anchor(r.b, r.d, jb, ia, f0);
-        const float *base = vp + ((int64_t)(ia[0] + TOMO_HALO) * sx + (int64_t)(ia[1] + TOMO_HALO) * sy + (ia[2] + TOMO_HALO));
-        const int cnt = min(TOMO_JB, r.j1 - jb);
-        float av = 0.f, a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
-        for (int jj = 0; jj < cnt; ++jj) {
-            const float t = (float)jj;
-            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
-            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-            const float wx = x - fx, wy = y - fy, wz = z - fz;
-            const float *q = base + ((int64_t)(int)fx * sx + (int64_t)(int)fy * sy + (int)fz);
-            const float v000 = q[0], v001 = q[1], v010 = q[sy], v011 = q[sy + 1];
-            const float v100 = q[sx], v101 = q[sx + 1], v110 = q[sx + sy], v111 = q[sx + sy + 1];
-            const float d00 = v001 - v000, d01 = v011 - v010, d10 = v101 - v100, d11 = v111 - v110;
-            const float c00 = fmaf(wz, d00, v000), c01 = fmaf(wz, d01, v010), c10 = fmaf(wz, d10, v100), c11 = fmaf(wz, d11, v110);
-            const float dz0 = fmaf(wy, d01 - d00, d00), dz1 = fmaf(wy, d11 - d10, d10);
-            const float gz = fmaf(wx, dz1 - dz0, dz0);
-            const float dy0 = c01 - c00, dy1 = c11 - c10;
-            const float e0 = fmaf(wy, dy0, c00), e1 = fmaf(wy, dy1, c10);
-            const float gy = fmaf(wx, dy1 - dy0, dy0);
-            const float gx = e1 - e0;
-            av += fmaf(wx, gx, e0);
-            const float sf = (float)(jb + jj) * sfs;
-            a0x += gx; a0y += gy; a0z += gz;
-            a1x = fmaf(sf, gx, a1x); a1y = fmaf(sf, gy, a1y); a1z = fmaf(sf, gz, a1z);
-        }
-        val += (double)av;
-        s0[0] += (double)a0x; s0[1] += (double)a0y; s0[2] += (double)a0z;
-        s1[0] += (double)a1x; s1[1] += (double)a1y; s1[2] += (double)a1z;
-    }
-    // per-ray pose Jacobian (utilities/ray_voxel_utilities.py:38-49)
     const double s[3] = {gc.s00[0] + ixc * gc.sdx, gc.s00[1], gc.s00[2] + iz * gc.sdz};
     double qv[3], gk[6];
 #pragma unroll
@@ -116,6 +69,68 @@ __global__ __launch_bounds__(256) void k_proj_grad(const ProjC *__restrict__ pcs
 }
 
 // ------------------------------------------------------------------------------------------------
+// projection + 6-DoF pose gradient.  Per sample only the interpolant's spatial gradient is formed
+// (3 values); S0 = sum_j grad_j and S1 = sum_j sf_j*grad_j are accumulated and the per-ray 9x3 pose
+// Jacobian is applied once (same algebra as src/ray_wt_grad.f90:136-149, SURVEY appendix A).
+// FUSED: multiply by the residual and reduce to 7 numbers per projection.
+// ------------------------------------------------------------------------------------------------
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_proj_grad(const ProjC *__restrict__ pcs, const GradC *__restrict__ gcs,
+                                                   const float *__restrict__ vp, float *__restrict__ proj,
+                                                   float *__restrict__ grad, const float *__restrict__ bvec,
+                                                   float *__restrict__ resid, double *__restrict__ red, TomoGeomC g,
+                                                   int row_order)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ix = blockIdx.y * 4 + wv, ip = blockIdx.z;
+    int iz = blockIdx.x * 64 + lane;
+    const bool valid = (ix < g.ndx) && (iz < g.ndz);
+    const int ixc = min(ix, g.ndx - 1);
+    if (iz >= g.ndz) iz = g.ndz - 1;
+    const ProjC &c = pcs[ip];
+    const GradC &gc = gcs[ip];
+    RayCtx r;
+    ray_setup(c, g, ixc, iz, valid, r, staged_box(vp, g));
+    const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
+    const int64_t sy = g.nzp, sx = (int64_t)g.nyp * g.nzp;
+    const float sfs = (float)(g.step / c.rlen);      // sf_j = (j*step)/|r_0|   ray_voxel_utilities.py:151
+    double val = 0.0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
+    for (int jb = r.j0; jb < r.j1; jb += TOMO_JB) {
+        int ia[3];
+        float f0[3];
+        tomo_block_anchor(r.b, r.d, jb, ia, f0);
+        const float *base = vp + ((int64_t)(ia[0] + TOMO_HALO) * sx + (int64_t)(ia[1] + TOMO_HALO) * sy + (ia[2] + TOMO_HALO));
+        const int cnt = min(TOMO_JB, r.j1 - jb);
+        float av = 0.f, a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float t = (float)jj;
+            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
+            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+            const float wx = x - fx, wy = y - fy, wz = z - fz;
+            const float *q = base + ((int64_t)(int)fx * sx + (int64_t)(int)fy * sy + (int)fz);
+            const float v000 = q[0], v001 = q[1], v010 = q[sy], v011 = q[sy + 1];
+            const float v100 = q[sx], v101 = q[sx + 1], v110 = q[sx + sy], v111 = q[sx + sy + 1];
+            const float d00 = v001 - v000, d01 = v011 - v010, d10 = v101 - v100, d11 = v111 - v110;
+            const float c00 = fmaf(wz, d00, v000), c01 = fmaf(wz, d01, v010), c10 = fmaf(wz, d10, v100), c11 = fmaf(wz, d11, v110);
+            const float dz0 = fmaf(wy, d01 - d00, d00), dz1 = fmaf(wy, d11 - d10, d10);
+            const float gz = fmaf(wx, dz1 - dz0, dz0);
+            const float dy0 = c01 - c00, dy1 = c11 - c10;
+            const float e0 = fmaf(wy, dy0, c00), e1 = fmaf(wy, dy1, c10);
+            const float gy = fmaf(wx, dy1 - dy0, dy0);
+            const float gx = e1 - e0;
+            av += fmaf(wx, gx, e0);
+            const float sf = (float)(jb + jj) * sfs;
+            a0x += gx; a0y += gy; a0z += gz;
+            a1x = fmaf(sf, gx, a1x); a1y = fmaf(sf, gy, a1y); a1z = fmaf(sf, gz, a1z);
+        }
+        val += (double)av;
+        s0[0] += (double)a0x; s0[1] += (double)a0y; s0[2] += (double)a0z;
+        s1[0] += (double)a1x; s1[1] += (double)a1y; s1[2] += (double)a1z;
+    }
+    grad_finish<FUSED>(gc, g, ixc, iz, valid, val, s0, s1, proj, grad, bvec, resid, red, row_order, lane, wv);
+}
+
+// ------------------------------------------------------------------------------------------------
 // projection + gradient, variant 2: the same sums as k_proj_grad with a cheaper sample (about 40 VALU instead of 59).
 //   * addressing as in k_fwd_v2: the sample blocks are walked in wave-uniform steps, the block bases are SGPR pairs and each
 //     lane carries ONE 32-bit byte offset for all eight corners (saddr + voffset loads): 3 integer ops instead of 14 64-bit ones;
@@ -155,13 +170,13 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
     const ProjC &c = pcs[ip];
     const GradC &gc = gcs[ip];
     RayCtx r;
-    ray_setup(c, g, ixc, iz, valid, r);
+    ray_setup(c, g, ixc, iz, valid, r, staged_box(vp, g));
     const bool nonempty = r.j1 > r.j0;
     const int J0 = __builtin_amdgcn_readfirstlane(wave_min_i32(nonempty ? r.j0 : INT_MAX));
     const int J1 = __builtin_amdgcn_readfirstlane(wave_max_i32(nonempty ? r.j1 : 0));
     const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
     const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;     // < 2^23 (tomo_check_geometry): signed 24-bit multiplies
-    const uint32_t abias4 = tomo_abias_bytes(sx4, sy4);
+    const uint32_t abias4 = tomo_abias_bytes(sx4, sy4) + tomo_lbias_bytes(sx4, sy4);
     const float sfs = (float)(g.step / c.rlen);
     // Eight DWORD gathers per sample, on purpose: with lanes on consecutive z cells a wave-wide global_load_dword costs
     // 4.8 cycles of the CU's texture-address/L1 pipeline, a dwordx2 (or x4) 17 (tools/gather_bench.hip), and that pipeline
@@ -177,13 +192,12 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
         const int64_t lin = ((int64_t)(ia[0] + TOMO_HALO) * g.nyp + (ia[1] + TOMO_HALO)) * g.nzp + (ia[2] + TOMO_HALO);
         const int64_t lin0 = readfirstlane_i64(lin);
         const int delta = (int)(lin - lin0);
-        const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(delta));
-        const char *sb00 = (const char *)(vp + (lin0 + m)) - abias4;      // cells relative to the anchor are signed: see tomo_block_anchor
+        const char *sb00 = (const char *)(vp + lin0) - abias4;            // cells relative to the anchor, and delta, are signed: fixed biases (tomo_raycore.h)
         const char *sb01 = sb00 + sy4;
         const char *sb10 = sb00 + sx4;
         const char *sb11 = sb10 + sy4;
         const char *sc00 = sb00 + four, *sc01 = sb01 + four, *sc10 = sb10 + four, *sc11 = sb11 + four;   // the z + 1 corners
-        const uint32_t off0 = (uint32_t)(delta - m) * 4u + abias4;
+        const uint32_t off0 = (uint32_t)(delta * 4) + abias4;
         const int lo = max(r.j0, jb) - jb, hi = min(r.j1, jb + TOMO_JB) - jb;      // this lane's samples of the block
         float av = 0.f;
         f32x2 a0xy = {0.f, 0.f}, a1xy = {0.f, 0.f}, az = {0.f, 0.f};              // (S0x, S0y), (S1x, S1y), (S0z, S1z)
@@ -246,57 +260,7 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
         s0[0] += (double)a0xy.x; s0[1] += (double)a0xy.y; s0[2] += (double)az.x;
         s1[0] += (double)a1xy.x; s1[1] += (double)a1xy.y; s1[2] += (double)az.y;
     }
-    const double s[3] = {gc.s00[0] + ixc * gc.sdx, gc.s00[1], gc.s00[2] + iz * gc.sdz};
-    double qv[3], gk[6];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) qv[a] = gc.ry[a][0] * s[0] + gc.ry[a][1] * s[1] + gc.ry[a][2] * s[2] + gc.t[a];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) gk[k] = gc.rzx[0][k] * s0[0] + gc.rzx[1][k] * s0[1] + gc.rzx[2][k] * s0[2];
-    gk[3] = gk[4] = gk[5] = 0.0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const double d3 = gc.a3[a][0] * qv[0] + gc.a3[a][1] * qv[1] + gc.a3[a][2] * qv[2];
-        const double d4 = gc.a4[a][0] * qv[0] + gc.a4[a][1] * qv[1] + gc.a4[a][2] * qv[2];
-        const double d5 = gc.a5[a][0] * s[0] + gc.a5[a][1] * s[1] + gc.a5[a][2] * s[2];
-        gk[3] += d3 * s0[a] + gc.app[0][a] * s1[a];
-        gk[4] += d4 * s0[a] + gc.app[1][a] * s1[a];
-        gk[5] += d5 * s0[a] + gc.app[2][a] * s1[a];
-    }
-    const size_t n_det = (size_t)g.ndx * g.ndz;
-    const size_t ray = (size_t)ixc * g.ndz + iz;
-    if (!FUSED) {
-        if (valid) {
-            proj[ray] = (float)val;
-            if (row_order == 0) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) grad[k * n_det + ray] = (float)gk[k];
-            } else {
-                grad[0 * n_det + ray] = (float)gk[0]; grad[1 * n_det + ray] = (float)gk[1]; grad[2 * n_det + ray] = (float)gk[2];
-                grad[3 * n_det + ray] = (float)gk[4]; grad[4 * n_det + ray] = (float)gk[5]; grad[5 * n_det + ray] = (float)gk[3];
-            }
-        }
-    } else {
-        double part[7] = {0, 0, 0, 0, 0, 0, 0};
-        if (valid) {
-            const float pv = (float)val;
-            const double res = (double)(bvec[(size_t)gc.b_row * n_det + ray] - pv);
-            if (resid) resid[(size_t)gc.slot * n_det + ray] = (float)res;
-            part[0] = 0.5 * res * res;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) part[1 + k] = -(double)(float)gk[k] * res;
-        }
-        __shared__ double sh[4][7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const double w = wave_sum_d(part[k]);
-            if (lane == 0) sh[wv][k] = w;
-        }
-        __syncthreads();
-        if (threadIdx.x < 7) {
-            const int k = threadIdx.x;
-            atomicAdd(&red[(size_t)gc.slot * 7 + k], sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k]);
-        }
-    }
+    grad_finish<FUSED>(gc, g, ixc, iz, valid, val, s0, s1, proj, grad, bvec, resid, red, row_order, lane, wv);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -340,13 +304,13 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
     const ProjC &c = pcs[ip];
     const GradC &gc = gcs[ip];
     RayCtx r;
-    ray_setup(c, g, ixc, iz, valid, r);
+    ray_setup(c, g, ixc, iz, valid, r, staged_box(vp, g));
     const bool nonempty = r.j1 > r.j0;
     const int J0 = __builtin_amdgcn_readfirstlane(wave_min_i32(nonempty ? r.j0 : INT_MAX));
     const int J1 = __builtin_amdgcn_readfirstlane(wave_max_i32(nonempty ? r.j1 : 0));
     const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
     const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;     // < 2^23 (tomo_check_geometry): signed 24-bit multiplies
-    const uint32_t abias4 = tomo_abias_bytes(sx4, sy4);
+    const uint32_t abias4 = tomo_abias_bytes(sx4, sy4) + tomo_lbias_bytes(sx4, sy4);
     const float sfs = (float)(g.step / c.rlen);
     double val = 0.0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
     for (int jb = J0; jb < J1; jb += TOMO_JB) {
@@ -356,18 +320,18 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
         const int64_t lin = ((int64_t)(ia[0] + TOMO_HALO) * g.nyp + (ia[1] + TOMO_HALO)) * g.nzp + (ia[2] + TOMO_HALO);
         const int64_t lin0 = readfirstlane_i64(lin);
         const int delta = (int)(lin - lin0);
-        const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(delta));
-        const char *sb00 = (const char *)(vp + (lin0 + m)) - abias4;      // cells relative to the anchor are signed: see tomo_block_anchor
+        const char *sb00 = (const char *)(vp + lin0) - abias4;            // cells relative to the anchor, and delta, are signed: fixed biases (tomo_raycore.h)
         const char *sb01 = sb00 + sy4;
         const char *sb10 = sb00 + sx4;
         const char *sb11 = sb10 + sy4;
-        const uint32_t off0 = (uint32_t)(delta - m) * 4u + abias4;
+        const uint32_t off0 = (uint32_t)(delta * 4) + abias4;
         const int lo = max(r.j0, jb) - jb, hi = min(r.j1, jb + TOMO_JB) - jb;      // this lane's samples of the block
         const bool has = hi > lo;
         const unsigned long long hm = __ballot(has);
         if (hm == 0ull) continue;                                                  // wave-uniform
-        const int LO = __builtin_amdgcn_readfirstlane(wave_min_i32(has ? lo : INT_MAX));
-        const int HI = __builtin_amdgcn_readfirstlane(wave_max_i32(has ? hi : 0));
+        // the wave's trip range from the uniform [J0, J1) (a lane that owns no sample of a trip is masked there): no per-block
+        // cross-lane min / max
+        const int LO = max(J0, jb) - jb, HI = min(J1, jb + TOMO_JB) - jb;
         // a lane with no sample in this block gathers where the first lane that has one takes its first sample
         uint32_t borrow;
         {
@@ -443,56 +407,7 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
         s0[0] += (double)a0x; s0[1] += (double)a0y; s0[2] += (double)a0z;
         s1[0] += (double)a1x; s1[1] += (double)a1y; s1[2] += (double)a1z;
     }
-    const double s[3] = {gc.s00[0] + ixc * gc.sdx, gc.s00[1], gc.s00[2] + iz * gc.sdz};
-    double qv[3], gk[6];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) qv[a] = gc.ry[a][0] * s[0] + gc.ry[a][1] * s[1] + gc.ry[a][2] * s[2] + gc.t[a];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) gk[k] = gc.rzx[0][k] * s0[0] + gc.rzx[1][k] * s0[1] + gc.rzx[2][k] * s0[2];
-    gk[3] = gk[4] = gk[5] = 0.0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const double d3 = gc.a3[a][0] * qv[0] + gc.a3[a][1] * qv[1] + gc.a3[a][2] * qv[2];
-        const double d4 = gc.a4[a][0] * qv[0] + gc.a4[a][1] * qv[1] + gc.a4[a][2] * qv[2];
-        const double d5 = gc.a5[a][0] * s[0] + gc.a5[a][1] * s[1] + gc.a5[a][2] * s[2];
-        gk[3] += d3 * s0[a] + gc.app[0][a] * s1[a];
-        gk[4] += d4 * s0[a] + gc.app[1][a] * s1[a];
-        gk[5] += d5 * s0[a] + gc.app[2][a] * s1[a];
-    }
-    const size_t n_det = (size_t)g.ndx * g.ndz;
-    const size_t ray = (size_t)ixc * g.ndz + iz;
-    if (!FUSED) {
-        if (valid) {
-            proj[ray] = (float)val;
-            if (row_order == 0) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) grad[k * n_det + ray] = (float)gk[k];
-            } else {
-                grad[0 * n_det + ray] = (float)gk[0]; grad[1 * n_det + ray] = (float)gk[1]; grad[2 * n_det + ray] = (float)gk[2];
-                grad[3 * n_det + ray] = (float)gk[4]; grad[4 * n_det + ray] = (float)gk[5]; grad[5 * n_det + ray] = (float)gk[3];
-            }
-        }
-    } else {
-        double part[7] = {0, 0, 0, 0, 0, 0, 0};
-        if (valid) {
-            const float pv = (float)val;
-            const double res = (double)(bvec[(size_t)gc.b_row * n_det + ray] - pv);
-            if (resid) resid[(size_t)gc.slot * n_det + ray] = (float)res;
-            part[0] = 0.5 * res * res;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) part[1 + k] = -(double)(float)gk[k] * res;
-        }
-        __shared__ double sh[4][7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const double w = wave_sum_d(part[k]);
-            if (lane == 0) sh[wv][k] = w;
-        }
-        __syncthreads();
-        if (threadIdx.x < 7) {
-            const int k = threadIdx.x;
-            atomicAdd(&red[(size_t)gc.slot * 7 + k], sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k]);
-        }
-    }
+    grad_finish<FUSED>(gc, g, ixc, iz, valid, val, s0, s1, proj, grad, bvec, resid, red, row_order, lane, wv);
 }
+
 

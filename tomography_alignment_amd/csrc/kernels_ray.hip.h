@@ -33,13 +33,56 @@ __device__ __forceinline__ int64_t readfirstlane_i64(int64_t v)
 // ------------------------------------------------------------------------------------------------
 // zero-halo staging
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pad(const float *__restrict__ vol, float *__restrict__ vp, TomoGeomC g)
+// The padded copy is followed by 8 ints: the box [lo, hi) of the volume's non-zero voxels (x, y, z lo; x, y, z hi; 2 spare),
+// found while the data streams through: k_pad leaves each (x, y) row's z range of non-zero values in `rowz`, k_box reduces the
+// rows (one work-group; no contended atomics -- on a dense volume a million rows would all want to update the same six words).
+// The ray-driven kernels clip every ray to the box (tomo_ray_range_box).
+#define TOMO_BOX_INTS 8
+__global__ __launch_bounds__(256) void k_pad(const float *__restrict__ vol, float *__restrict__ vp, TomoGeomC g, int2 *__restrict__ rowz)
 {
     const int row = blockIdx.x;            // ix*ny + iy
     const int ix = row / g.ny, iy = row - ix * g.ny;
     const float *src = vol + (size_t)row * g.nz;
     float *dst = vp + ((size_t)(ix + TOMO_HALO) * g.nyp + (iy + TOMO_HALO)) * g.nzp + TOMO_HALO;
-    for (int z = threadIdx.x; z < g.nz; z += blockDim.x) dst[z] = src[z];
+    int zlo = INT_MAX, zhi = 0;
+    for (int z = threadIdx.x; z < g.nz; z += blockDim.x) {
+        const float v = src[z];
+        dst[z] = v;
+        if (v != 0.f) { zlo = min(zlo, z); zhi = max(zhi, z + 1); }       // NaN != 0: kept
+    }
+    __shared__ int sh[8];
+    zlo = wave_min_i32(zlo);
+    zhi = wave_max_i32(zhi);
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = zlo; sh[4 + (threadIdx.x >> 6)] = zhi; }
+    __syncthreads();
+    if (threadIdx.x == 0) rowz[row] = make_int2(min(min(sh[0], sh[1]), min(sh[2], sh[3])), max(max(sh[4], sh[5]), max(sh[6], sh[7])));
+}
+
+__global__ __launch_bounds__(1024) void k_box(const int2 *__restrict__ rowz, TomoGeomC g, int *__restrict__ box)
+{
+    int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {0, 0, 0};
+    const int n_rows = g.nx * g.ny;
+    for (int row = threadIdx.x; row < n_rows; row += 1024) {
+        const int2 z = rowz[row];
+        if (z.y > 0) {
+            const int ix = row / g.ny, iy = row - ix * g.ny;
+            lo[0] = min(lo[0], ix); hi[0] = max(hi[0], ix + 1);
+            lo[1] = min(lo[1], iy); hi[1] = max(hi[1], iy + 1);
+            lo[2] = min(lo[2], z.x); hi[2] = max(hi[2], z.y);
+        }
+    }
+    __shared__ int sh[16][6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int l = wave_min_i32(lo[a]), h = wave_max_i32(hi[a]);
+        if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][a] = l; sh[threadIdx.x >> 6][3 + a] = h; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        int v = sh[0][threadIdx.x];
+        for (int w = 1; w < 16; ++w) v = threadIdx.x < 3 ? min(v, sh[w][threadIdx.x]) : max(v, sh[w][threadIdx.x]);
+        box[threadIdx.x] = v;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_unpad(float *__restrict__ vol, const float *__restrict__ vp, TomoGeomC g, int accumulate)
@@ -63,7 +106,10 @@ static int stage_volume(tomo_ctx *ctx, const float *d_vol)
         TOMO_HIP(ctx, hipMemsetAsync(ctx->d_volpad, 0, ctx->volpad_elems * sizeof(float), ctx->stream));
         ctx->halo_dirty = false;
     }
-    TOMO_LAUNCH(ctx, "k_pad", k_pad, dim3(g.nx * g.ny), dim3(256), 0, d_vol, ctx->d_volpad, g);
+    int *box = (int *)(ctx->d_volpad + ctx->volpad_elems);
+    int2 *rowz = (int2 *)(box + TOMO_BOX_INTS);
+    TOMO_LAUNCH(ctx, "k_pad", k_pad, dim3(g.nx * g.ny), dim3(256), 0, d_vol, ctx->d_volpad, g, rowz);
+    TOMO_LAUNCH(ctx, "k_box", k_box, dim3(1), dim3(1024), 0, (const int2 *)rowz, g, box);
     return TOMO_OK;
 }
 
@@ -75,16 +121,23 @@ struct RayCtx {
     int j0, j1;
 };
 
-__device__ __forceinline__ void ray_setup(const ProjC &c, const TomoGeomC &g, int ix, int iz, bool valid, RayCtx &r)
+// `box`: the 6 ints behind the staged volume (k_pad) for kernels that READ it -- rays are clipped to the non-zero voxels; nullptr
+// for the scatter kernel, which must visit every sample inside the volume
+__device__ __forceinline__ void ray_setup(const ProjC &c, const TomoGeomC &g, int ix, int iz, bool valid, RayCtx &r, const int *box = nullptr)
 {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         r.b[a] = c.p0[a] + (double)ix * c.u[a] + (double)iz * c.w[a];
         r.d[a] = c.d[a];
     }
-    tomo_ray_range(r.b, r.d, c.n, g.nx, g.ny, g.nz, r.j0, r.j1);
+    if (box) {
+        const int lo[3] = {box[0], box[1], box[2]}, hi[3] = {box[3], box[4], box[5]};      // wave-uniform: scalar loads
+        tomo_ray_range_box(r.b, r.d, c.n, lo, hi, r.j0, r.j1);
+    } else
+        tomo_ray_range(r.b, r.d, c.n, g.nx, g.ny, g.nz, r.j0, r.j1);
     if (!valid) r.j0 = r.j1 = 0;
 }
+__device__ __forceinline__ const int *staged_box(const float *vp, const TomoGeomC &g) { return (const int *)(vp + (size_t)g.nxp * g.nyp * g.nzp); }
 
 // trilinear value from the 8 loaded corners: v000 + wz*(v001-v000) ... == sum rec*wx*wy*wz of
 // src/ray_wt_grad.f90:143-145 with wf = 1-wc (utilities/ray_voxel_utilities.py:98-99)
@@ -111,7 +164,7 @@ __global__ __launch_bounds__(256) void k_fwd_v1(const ProjC *__restrict__ pcs, c
     if (ix >= g.ndx || iz >= g.ndz) return;
     const ProjC &c = pcs[ip];
     RayCtx r;
-    ray_setup(c, g, ix, iz, true, r);
+    ray_setup(c, g, ix, iz, true, r, staged_box(vp, g));
     const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
     const int64_t sy = g.nzp, sx = (int64_t)g.nyp * g.nzp;
     double total = 0.0;
@@ -152,13 +205,13 @@ __global__ __launch_bounds__(256) void k_fwd_v2(const ProjC *__restrict__ pcs, c
     if (!valid) iz = g.ndz - 1;                    // keep the lane's arithmetic in range; it contributes nothing
     const ProjC &c = pcs[ip];
     RayCtx r;
-    ray_setup(c, g, ix, iz, valid, r);
+    ray_setup(c, g, ix, iz, valid, r, staged_box(vp, g));
     const bool nonempty = r.j1 > r.j0;
     const int J0 = __builtin_amdgcn_readfirstlane(wave_min_i32(nonempty ? r.j0 : INT_MAX));
     const int J1 = __builtin_amdgcn_readfirstlane(wave_max_i32(nonempty ? r.j1 : 0));
     const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
     const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;     // < 2^23 (tomo_check_geometry): signed 24-bit multiplies
-    const uint32_t abias4 = tomo_abias_bytes(sx4, sy4);
+    const uint32_t abias4 = tomo_abias_bytes(sx4, sy4) + tomo_lbias_bytes(sx4, sy4);
     // dword gathers on purpose (a wave-wide dwordx2 costs 3.5x a dword in the L1 pipeline, tools/gather_bench.hip): the z + 1
     // bases carry an offset the compiler cannot see through, so it does not fuse the corner pairs
     int four;
@@ -170,15 +223,14 @@ __global__ __launch_bounds__(256) void k_fwd_v2(const ProjC *__restrict__ pcs, c
         tomo_block_anchor(r.b, r.d, jb, ia, f0);
         const int64_t lin = ((int64_t)(ia[0] + TOMO_HALO) * g.nyp + (ia[1] + TOMO_HALO)) * g.nzp + (ia[2] + TOMO_HALO);
         const int64_t lin0 = readfirstlane_i64(lin);
-        const int delta = (int)(lin - lin0);       // neighbouring rays at the same j: a few rows apart
-        const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(delta));
-        // cells relative to the (middle-of-block) anchor are signed: base lowered, lane offset raised by TOMO_ABIAS cells per axis
-        const char *sb00 = (const char *)(vp + (lin0 + m)) - abias4;
+        const int delta = (int)(lin - lin0);       // neighbouring rays at the same j: a few rows apart (< 66 cells per axis: lbias4)
+        // cells relative to the (middle-of-block) anchor are signed and so is delta: base lowered, lane offset raised by a fixed bias
+        const char *sb00 = (const char *)(vp + lin0) - abias4;
         const char *sb01 = sb00 + sy4;
         const char *sb10 = sb00 + sx4;
         const char *sb11 = sb10 + sy4;
         const char *sc00 = sb00 + four, *sc01 = sb01 + four, *sc10 = sb10 + four, *sc11 = sb11 + four;
-        const uint32_t off0 = (uint32_t)(delta - m) * 4u + abias4;
+        const uint32_t off0 = (uint32_t)(delta * 4) + abias4;
         const int lo = max(r.j0, jb) - jb, hi = min(r.j1, jb + TOMO_JB) - jb;
         float acc = 0.f;
         for (int jj = lo; jj < hi; ++jj) {

@@ -28,6 +28,7 @@ struct tomo_ctx {
     // padded scratch volume (zero halo) and its state
     float *d_volpad = nullptr;
     size_t volpad_elems = 0;
+    size_t volpad_rows = 0;             // nx * ny the row scratch behind the padded copy was sized for
     bool halo_dirty = true;
     bool wide_rows = false;             // TOMO_GEOM_WIDE_ROWS: a padded x-row pitch >= 2^24 bytes -- the 24-bit-multiply kernels are not used
     const void *staged_src = nullptr;   // device pointer whose contents the padded copy currently holds

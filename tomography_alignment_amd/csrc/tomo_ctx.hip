@@ -187,7 +187,8 @@ extern "C" int tomo_check_geometry(const tomo_geom *g, int *flags)
     const size_t nxp = (size_t)g->nx + 2 * TOMO_HALO, nyp = (size_t)g->ny + 2 * TOMO_HALO, nzp = (size_t)g->nz + 2 * TOMO_HALO;
     if (nxp * nyp * nzp >= ((size_t)1 << 31)) return tomo_fail(nullptr, TOMO_ERR_UNSUPPORTED, "set_geometry: padded volume exceeds 2^31 voxels");
     // the SGPR-base kernels (k_fwd_v2, k_proj_grad_v2/_v3) form lane offsets with SIGNED 24-bit multiplies: cell * (row pitch in bytes)
-    if (nyp * nzp * 4 >= ((size_t)1 << 23) || nzp * 4 >= ((size_t)1 << 23)) { if (flags) *flags |= TOMO_GEOM_WIDE_ROWS; }
+    // ... and bias a wave's lane offsets by 66 cells per axis, which covers 64 rays only while the detector-z pitch <= 1 voxel
+    if (nyp * nzp * 4 >= ((size_t)1 << 23) || nzp * 4 >= ((size_t)1 << 23) || !(fabs(g->det_dz) <= 1.0 + 1e-9)) { if (flags) *flags |= TOMO_GEOM_WIDE_ROWS; }
     return TOMO_OK;
 }
 
@@ -207,13 +208,15 @@ extern "C" int tomo_set_geometry(tomo_ctx *ctx, const tomo_geom *g)
     size_t pe = (size_t)c.nxp * c.nyp * c.nzp;
     ctx->wide_rows = (gflags & TOMO_GEOM_WIDE_ROWS) != 0;
     TOMO_HIP(ctx, hipSetDevice(ctx->device));
-    if (pe != ctx->volpad_elems) {
+    if (pe != ctx->volpad_elems || (size_t)g->nx * g->ny != ctx->volpad_rows) {
         TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_volpad) (void)hipFree(ctx->d_volpad);
         ctx->d_volpad = nullptr;
         ctx->volpad_elems = 0;
-        TOMO_HIP(ctx, hipMalloc((void **)&ctx->d_volpad, pe * sizeof(float)));
+        // + the non-zero box behind it (TOMO_BOX_INTS = 8 ints) + one int2 per (x, y) row for its reduction (k_pad, k_box)
+        TOMO_HIP(ctx, hipMalloc((void **)&ctx->d_volpad, (pe + 8 + 2 * (size_t)g->nx * g->ny) * sizeof(float)));
         ctx->volpad_elems = pe;
+        ctx->volpad_rows = (size_t)g->nx * g->ny;
     }
     ctx->halo_dirty = true;
     ctx->staged_src = nullptr;

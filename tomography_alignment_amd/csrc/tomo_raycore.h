@@ -139,19 +139,29 @@ TOMO_HD void tomo_clip_axis(double b, double d, double lo, double hi, double &t0
 
 // Sample range [j0, j1) of a ray outside which every corner of every sample is out of bounds
 // (floor(p_a) in [-1, n_a-1] <=> p_a in [-1, n_a)).  Rounded outward by 1e-6 samples only, so all
-// computed floors stay inside the TOMO_HALO=2 padding (float32 in-block error ~1e-5 voxel).
-TOMO_HD void tomo_ray_range(const double b[3], const double d[3], int n, int nx, int ny, int nz, int &j0, int &j1)
+// computed floors stay inside the TOMO_HALO=2 padding (float32 in-block error ~1e-6 voxel).
+// With a box [lo_a, hi_a) of the NON-ZERO voxels (found while the volume is staged, k_pad) the range shrinks to the samples
+// that can see one of them: floor(p_a) in [lo_a - 1, hi_a - 1] <=> p_a in [lo_a - 1, hi_a) -- the others add exactly 0 to a
+// projection and to its gradient (all 8 corners are 0), the ray-driven analogue of the tile kernels' all-zero-tile exit.
+TOMO_HD void tomo_ray_range_box(const double b[3], const double d[3], int n, const int lo[3], const int hi[3], int &j0, int &j1)
 {
+    j0 = j1 = 0;
+    if (hi[0] <= lo[0] || hi[1] <= lo[1] || hi[2] <= lo[2]) return;      // nothing non-zero
     double t0 = 0.0, t1 = (double)(n - 1);
-    tomo_clip_axis(b[0], d[0], -1.0, (double)nx, t0, t1);
-    tomo_clip_axis(b[1], d[1], -1.0, (double)ny, t0, t1);
-    tomo_clip_axis(b[2], d[2], -1.0, (double)nz, t0, t1);
-    if (!(t0 <= t1)) { j0 = 0; j1 = 0; return; }
+    tomo_clip_axis(b[0], d[0], (double)lo[0] - 1.0, (double)hi[0], t0, t1);
+    tomo_clip_axis(b[1], d[1], (double)lo[1] - 1.0, (double)hi[1], t0, t1);
+    tomo_clip_axis(b[2], d[2], (double)lo[2] - 1.0, (double)hi[2], t0, t1);
+    if (!(t0 <= t1)) return;
     j0 = (int)ceil(t0 - 1e-6);
     j1 = (int)floor(t1 + 1e-6) + 1;
     if (j0 < 0) j0 = 0;
     if (j1 > n) j1 = n;
     if (j1 < j0) j1 = j0;
+}
+TOMO_HD void tomo_ray_range(const double b[3], const double d[3], int n, int nx, int ny, int nz, int &j0, int &j1)
+{
+    const int lo[3] = {0, 0, 0}, hi[3] = {nx, ny, nz};
+    tomo_ray_range_box(b, d, n, lo, hi, j0, j1);
 }
 
 // Block anchor: the integer floor of the block's MIDDLE position, so the float32 in-block coordinates x = f0 + jj*d stay within
@@ -172,5 +182,10 @@ TOMO_HD void tomo_block_anchor(const double b[3], const double d[3], int jb, int
     }
 }
 TOMO_HD uint32_t tomo_abias_bytes(uint32_t sx4, uint32_t sy4) { return (uint32_t)TOMO_ABIAS * (sx4 + sy4 + 4u); }
+// The lanes of a wave are 64 consecutive detector-z rays: their anchors differ from lane 0's by at most 64 |w_a| + 1 <= 65 cells
+// per axis (|w| = detector-z pitch in voxels <= 1: checked when the poses are staged), so a fixed bias of 66 cells per axis makes
+// every lane's offset relative to lane 0's anchor non-negative -- no per-block wave-wide minimum (six cross-lane round trips).
+#define TOMO_LBIAS 66
+TOMO_HD uint32_t tomo_lbias_bytes(uint32_t sx4, uint32_t sy4) { return (uint32_t)TOMO_LBIAS * (sx4 + sy4 + 4u); }
 
 #endif  // TOMO_RAYCORE_H_

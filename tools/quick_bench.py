@@ -23,13 +23,16 @@ def poses(n_proj, tilt, rng):
     return _lib.poses_array(phi, a, b, xyz, np.zeros(3))
 
 
-def run(N, n_proj, what, tilt=True, reps=2, opts=None):
+def run(N, n_proj, what, tilt=True, reps=2, opts=None, shepp=False):
     rng = np.random.default_rng(0)
     geo = Geometry(n_proj, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
     be = HipBackend(geo)
     for k, v in (opts or {}).items():
         be.ctx.set_option(k, v)
     vol = be.zeros(N ** 3); be.fill(vol, 1.0)
+    if shepp:
+        from tomography_alignment_amd.utilities.generate_phantom import SHEPP_LOGAN
+        be.phantom(vol, (N, N, N), SHEPP_LOGAN)
     prj = be.zeros(n_proj * N * N); be.fill(prj, 1.0)
     P = poses(n_proj, tilt, rng)
     grad = be.empty(6 * N * N) if what == "pg" else None
@@ -43,8 +46,8 @@ def run(N, n_proj, what, tilt=True, reps=2, opts=None):
         be.ctx.timer_start(); fn(); ms = be.ctx.timer_stop(); best = min(best, ms)
     alg = {"fwd": 4 * N ** 3 + 4 * N * N, "adj": 8 * N ** 3 + 4 * N * N, "bpv": 8 * N ** 3 + 4 * N * N,
            "cg": 4 * N ** 3 + 4 * N * N + 28, "pg": 4 * N ** 3 + 28 * N * N}[what] * n_proj
-    print("%-4s N=%4d n_proj=%4d tilt=%g opts=%s : %9.2f ms  alg %.1f GB/s  (%.1f%% of 8 TB/s)  [%.3f ms/angle]"
-          % (what, N, n_proj, tilt, opts, best, alg / best / 1e6, alg / best / 1e6 / 80.0, best / n_proj), flush=True)
+    print("%-4s N=%4d n_proj=%4d tilt=%g shepp=%d opts=%s : %9.2f ms  alg %.1f GB/s  (%.1f%% of 8 TB/s)  [%.3f ms/angle]"
+          % (what, N, n_proj, tilt, int(shepp), opts, best, alg / best / 1e6, alg / best / 1e6 / 80.0, best / n_proj), flush=True)
     del vol, prj
     be.ctx.close()
 
@@ -57,11 +60,11 @@ if __name__ == "__main__":
         opts = {}
         for kv in parts[3:]:
             k, v = kv.split("=")
-            if k == "tilt":
+            if k in ("tilt", "shepp"):
                 continue
             opts[k] = int(v)
         tilt = 1.0
         for kv in parts[3:]:
             if kv.startswith("tilt="):
                 tilt = float(kv[5:])
-        run(N, n_proj, what, tilt=tilt, opts=opts)
+        run(N, n_proj, what, tilt=tilt, opts=opts, shepp=any(kv == 'shepp=1' for kv in parts[3:]))
