@@ -132,8 +132,10 @@ def test_fortran_row_order_and_matrix_free_golden(PM, shepp32):
     det = be.upload(g2["y"])
     vol = be.empty(32 ** 3)
     be.backproject_voxel(poses, det, vol)
-    # A6: the Fortran rotates voxel centres in float32 (ulp 2e-6 at |x|~16): bilinear weights differ by ~1e-5
-    assert rel_max(vol.download(), g4["atx"]) < 3e-5
+    # A6: back_project_ is float32 throughout; k_bp_voxel performs the reference's float32 operations in the reference's order
+    e_a6 = rel_max(vol.download(), g4["atx"])
+    print("A6 back_project vs the Fortran: rel-max %.2e" % e_a6)
+    assert e_a6 < 2e-6
     vdev = be.upload(shepp32)
     pr, gd = be.empty(1024), be.empty(6 * 1024)
     for i in range(3):                                                          # A7 row order tx,ty,tz,alpha,beta,phi
@@ -296,7 +298,11 @@ def test_voxel_splat_vs_reference_golden(PM):
         img, grad = voxel_utilities.forward_proj_grad(geo, g["alpha"][i], g["beta"][i], g["phi"][i], g["xyz"][i], x)
         assert grad.shape == (6, 256)
         assert rel_max(img, g["img%d" % i]) < TOL
-        assert rel_max(grad, g["grad%d" % i]) < 3e-5      # float32 sums of ~16 terms in atomic order vs the Fortran's serial order
+        # float32 atomics add the reference's float32 terms in another order; tests/test_oracle_golden.py::
+        # test_voxel_splat_gradient_conditioning measures that order to be worth ~1e-7 and the cancellation a factor 4
+        e_a9 = rel_max(grad, g["grad%d" % i])
+        print("A9 voxel-splat gradient vs the reference, pose %d: rel-max %.2e (image %.2e)" % (i, e_a9, rel_max(img, g["img%d" % i])))
+        assert e_a9 < TOL
     P = PM(geo_pair(2, 16)[0])
     P.projection_matrix(alpha=g["alpha"], beta=g["beta"], phi=g["phi"], xyz_shift=g["xyz"])
     wts, dets, dats = P._forward_voxel()

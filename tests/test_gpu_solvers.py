@@ -30,8 +30,11 @@ def test_sirt_vs_reference_golden(shepp32, tag, positivity, use_gt):
     assert np.array_equal(s.V == 0, g["V"] == 0) and rel_max(inv(s.V), inv(g["V"])) < 1e-5
     rec, err = s.run_main_iteration(niter=10, positivity=positivity)
     assert rec.shape == (32, 32, 32)
-    assert rel_max(rec, g["rec_" + tag]) < 5e-5          # 10 iterations of float32 operators
-    assert np.allclose(err, g["err_" + tag], rtol=5e-5)
+    e_rec, e_err = rel_max(rec, g["rec_" + tag]), float(np.max(np.abs(err - g["err_" + tag]) / g["err_" + tag]))
+    print("SIRT x10 vs the reference (%s): rec rel-max %.2e, rms_error rel %.2e" % (tag, e_rec, e_err))
+    # 10 iterations: the reference's own iterate moves by 5x (rel-max) an operator perturbation of the kernels' size (1-2e-6 per
+    # application), tests/test_oracle_golden.py::test_sirt_sensitivity_to_operator_rounding -> 2e-5; rms_error is a norm ratio
+    assert e_rec < 2e-5 and e_err < 1e-5
 
 
 def test_sharded_sirt_world_of_one_matches_plain(shepp32):
@@ -42,10 +45,14 @@ def test_sharded_sirt_world_of_one_matches_plain(shepp32):
     angles = np.array([g["phi"], g["alpha"], g["beta"]]).T
     s = sirt_mpi.SIRT(SingleComm(), geo, g["b"].copy(), angles, g["xyz"], options={})
     rec, err = s.run_main_iteration(niter=10)
-    assert rel_max(rec, g["rec_plain"]) < 5e-5
+    assert rel_max(rec, g["rec_plain"]) < 2e-5
 
 
 def test_cgls_vs_restated_reference(shepp32):
+    """RESTATEMENT-ONLY parity: the reference's recon/cgls.py cannot be imported (it needs a `utilities.linear_operators` module
+    the reference does not contain, :3; `self.method` is undefined, :51), so there is no golden vector -- the device-resident
+    CGLS is compared with the oracle's reading of that source (oracle/oracle.py::cgls), nothing more.  CG amplifies rounding
+    (the search directions lose conjugacy at float32): 8 iterations are held to 2e-4; the measured value is printed."""
     from oracle import oracle as orc
     from tomography_alignment_amd.recon import cgls
     g = golden("g5_sirt")
@@ -56,6 +63,7 @@ def test_cgls_vs_restated_reference(shepp32):
     want, want_err = orc.cgls(lambda x: orc.forward(og, x, **kw).astype(np.float32).ravel(),
                               lambda y: orc.adjoint(og, y, **kw).astype(np.float32), 32 ** 3, g["b"], 8)
     rec, err = cgls.CGLS(geo, g["b"].copy(), angles, g["xyz"]).run_main_iteration(niter=8)
+    print("CGLS x8 vs the oracle's restatement: rec rel-max %.2e, rms rel %.2e" % (rel_max(rec, want), float(np.max(np.abs(err - want_err) / want_err))))
     assert rel_max(rec, want) < 2e-4 and np.allclose(err, want_err, rtol=2e-4)
 
 

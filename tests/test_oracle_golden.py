@@ -191,3 +191,38 @@ def _last_zero(shape):
     m = np.ones((3,) + shape)
     m[0][-1], m[1][:, -1], m[2][:, :, -1] = 0, 0, 0
     return m
+
+
+def test_voxel_splat_gradient_conditioning():
+    """Where the 3e-5 bound of the GPU's voxel-splat GRADIENT parity comes from (tests/test_gpu_parity.py).
+    src/vox_wt_grad.f90:1-55 adds, per detector pixel, float32 terms of both signs that largely cancel.  Measured here on the
+    golden inputs: (i) the ORDER of the additions is harmless -- the reference's float32 serial sums equal the same float32 terms
+    added in float64 to ~1e-7; (ii) the cancellation is not -- sum|term| exceeds max|sum| by the factor printed, so one float32
+    ulp (6e-8) in a term's factors (der, the bilinear weights: computed in float64 and cast by the reference's Python, by other
+    float64 operations in any independent implementation) moves the result by 6e-8 x that factor relative to its maximum."""
+    g = golden("g8_voxel_splat")
+    x = golden("g7_phantom")["shepp16"].astype(np.float32).ravel()
+    worst_order, worst_cancel = 0.0, 0.0
+    for i in range(2):
+        G = geo(1, 16)
+        fx, fz, ax, az = orc._vox_floor_alpha(G, g["alpha"][i], g["beta"][i], g["phi"][i], g["xyz"][i], g["cor"][i])
+        der = np.ascontiguousarray(orc.vox_derivative_rigid(G.vox_centers, g["alpha"][i], g["beta"][i], g["phi"][i], g["xyz"][i]), np.float32)
+        ndx, ndz = 16, 16
+        exact, mag = np.zeros((6, ndz * ndx)), np.zeros((6, ndz * ndx))
+        one = np.float32(1.0)
+        for c in range(2):
+            for a in range(2):
+                xx, zz = fx + a, fz + c
+                ok = (xx >= 0) & (xx < ndx) & (zz >= 0) & (zz < ndz)
+                f0 = [[one - az, -one * (one - az)], [az, -one * az]][c][a]          # src/vox_wt_grad.f90:27-28,33-34,39-40,45-46
+                f2 = [[one - ax, ax], [-one * (one - ax), -one * ax]][c][a]
+                o = (zz * ndx + xx)[ok]          # pixel index of the returned (6, ndz * ndx) array
+                for k in range(6):
+                    t0, t2 = (der[k, 0] * f0 * x).astype(np.float32), (der[k, 2] * f2 * x).astype(np.float32)   # float32 terms, as the Fortran forms them
+                    np.add.at(exact[k], o, (t0 + t2)[ok].astype(np.float64))
+                    np.add.at(mag[k], o, (np.abs(t0) + np.abs(t2))[ok].astype(np.float64))
+        worst_order = max(worst_order, rel_max(g["grad%d" % i].reshape(6, -1), exact))
+        worst_cancel = max(worst_cancel, max(mag[k].max() / np.abs(exact[k]).max() for k in range(6)))
+    print("voxel-splat gradient: reference float32 serial sums vs the same terms in float64: rel-max %.1e; sum|term| / max|sum| up to %.0f"
+          % (worst_order, worst_cancel))
+    assert worst_order < 1e-6 and 6e-8 * worst_cancel * 4 < 3e-5        # a few ulps per term x the cancellation stay inside the GPU test's bound

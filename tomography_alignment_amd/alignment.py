@@ -4,9 +4,9 @@ Batched per-projection pose alignment: the inner loop of the reference's example
 optimisers advancing together, so that each round of function evaluations is ONE launch of the fused
 cost/gradient kernel over many projections (tomo_cost_grad) instead of n_proj separate launches.
 
-scipy's L-BFGS-B is kept as the optimiser (drop-in semantics): every projection runs its own
-`optimize.minimize` in a worker thread; an evaluation request blocks until the scheduler has collected the pending
-requests of all live workers, evaluated them in one batch and handed the results back.
+scipy's L-BFGS-B is kept as the optimiser (drop-in semantics): a fixed pool of worker threads each runs one projection's
+`optimize.minimize` at a time; an evaluation request blocks until the scheduler has collected the pending
+requests of the live workers, evaluated them in one batch and handed the results back.
 
 Multi-GPU: projections are independent -- rank r aligns np.array_split(arange(n_proj), P)[r] with a
 replicated volume and no collective inside the optimiser; the 4 recovered parameters per projection are gathered
@@ -99,6 +99,12 @@ class _Scheduler(object):
             del self.events[i]
             self.wake.notify()
 
+    def swap(self, i, j):
+        """Worker finished projection i and starts projection j: the number of live optimisers does not change."""
+        with self.lock:
+            del self.events[i]
+            self.events[j] = threading.Event()
+
     def _ready(self):
         n = len(self.pending)
         return n > 0 and (n == self.live or (self.live > self.small and 2 * n >= self.live))
@@ -173,54 +179,53 @@ def align_projections(backend, rec, projections, phi, letters="xzab", x0=None, a
     opts = {"disp": False}
     opts.update(options or {})
 
-    # a rolling pool: at most max_threads optimisers are live; when one converges the next projection starts, so the
-    # batches stay full until the very end instead of draining once per chunk
+    # a fixed pool of worker threads (at most max_threads): each runs one projection's optimiser at a time and takes the next
+    # projection from the queue when it converges, so the batches stay full until the very end instead of draining once per
+    # chunk -- and 720 projections cost 256 threads, not 720
+    import collections
     sched = _Scheduler(ev)
     errors = []
-    slots = threading.Semaphore(max_threads)
-    state = {"started": 0}
+    order = [int(i) for i in indices]
+    n_workers = min(max_threads, len(order))
+    queue = collections.deque(order[n_workers:])
+    qlock = threading.Lock()
+
+    def solve(i):
+        def fun(p):
+            pose = base[i].copy()
+            pose[cols] += p
+            cost, g6 = sched.request(i, pose)
+            return cost, g6[rows] * scale
+        res = optimize.minimize(fun, x0[i], jac=True, method="L-BFGS-B", bounds=bounds, options=opts)
+        out_x[i], out_f[i], out_n[i] = res.x, res.fun, res.nfev
 
     def work(i):
         try:
-            def fun(p):
-                pose = base[i].copy()
-                pose[cols] += p
-                cost, g6 = sched.request(i, pose)
-                return cost, g6[rows] * scale
-            res = optimize.minimize(fun, x0[i], jac=True, method="L-BFGS-B", bounds=bounds, options=opts)
-            out_x[i], out_f[i], out_n[i] = res.x, res.fun, res.nfev
+            while True:
+                solve(i)
+                with qlock:
+                    nxt = queue.popleft() if (queue and not errors) else None
+                if nxt is None:
+                    break
+                sched.swap(i, nxt)
+                i = nxt
         except Exception as e:      # noqa: BLE001
             errors.append(e)
         finally:
             sched.leave(i)
-            slots.release()
 
-    def spawn():
-        first = [int(i) for i in indices[:max_threads]]
-        for i in first:                                # the first pool is registered as a whole, so that the first launch
-            slots.acquire()                            # waits for all of it instead of firing on the first arrival
-            sched.enter(i)
-        for i in first:
-            threading.Thread(target=work, args=(i,), daemon=True).start()
-        for i in indices[max_threads:]:
-            slots.acquire()
-            if errors:
-                slots.release()
-                break
-            sched.enter(int(i))
-            threading.Thread(target=work, args=(int(i),), daemon=True).start()
-        with sched.lock:
-            state["started"] = -1                      # nobody left to start
-            sched.wake.notify()
-
-    spawner = threading.Thread(target=spawn, daemon=True)
+    for i in order[:n_workers]:                        # the first pool is registered as a whole, so that the first launch waits
+        sched.enter(i)                                 # for all of it instead of firing on the first arrival
+    threads = [threading.Thread(target=work, args=(i,), daemon=True) for i in order[:n_workers]]
     switch = sys.getswitchinterval()
     sys.setswitchinterval(min(switch, 5e-4))           # hundreds of short-running threads: hand the GIL over promptly
-    spawner.start()
+    for t in threads:
+        t.start()
     try:
-        sched.run(lambda: state["started"] == -1)
+        sched.run(lambda: True)                        # returns once no worker is live (the queue is drained by then)
     finally:
-        spawner.join()
+        for t in threads:
+            t.join(timeout=60)
         ev.close()
         sys.setswitchinterval(switch)
     if errors:

@@ -294,34 +294,55 @@ __global__ __launch_bounds__(256) void k_adj_v1(const ProjC *__restrict__ pcs, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// voxel-driven bilinear back-projector (src/back_projection.f90:25-32): one voxel per work-item,
-// lanes along z, loop over projections with the accumulator in a register; the voxel centre is
-// transformed on the fly (the reference re-reads a (3,n_vox) voxel_centers array per projection).
+// voxel-driven bilinear back-projector (src/back_projection.f90:25-32): one voxel per work-item, lanes along z, loop over
+// projections with the accumulator in a register; the voxel centre is transformed on the fly (the reference re-reads a
+// (3, n_vox) voxel_centers array per projection).
+// FLOAT32 IN THE REFERENCE'S OWN OPERATION ORDER: the Fortran is real(kind=4) throughout -- x' = Ry (Rx (Rz c) + t) as three
+// float32 matrix-vector products (src/external_back_projection.f90:20-25), u = x'_1 - origin_1, alpha = u - floor(u), the four
+// products det * wx * wz added in the order of :54-65 -- and a float32 voxel coordinate at |x| ~ N/2 carries an ulp of N * 6e-8
+// voxel, so a float64 transform gives weights that differ from the reference's by ~1e-5.  Every operation below is the
+// reference's, unfused (__fmul_rn / __fadd_rn: no FMA contraction), with the rotation matrices built on the host by the same
+// cosf / sinf: parity with back_project_ to float32 rounding instead of 3e-5.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bp_mv3(const float m[3][3], const float x[3], float o[3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = __fadd_rn(__fadd_rn(__fmul_rn(m[i][0], x[0]), __fmul_rn(m[i][1], x[1])), __fmul_rn(m[i][2], x[2]));
+}
+
 __global__ __launch_bounds__(256) void k_bp_voxel(const BpC *__restrict__ cs, int n_proj, const float *__restrict__ det,
-                                                  float *__restrict__ vol, TomoGeomC g)
+                                                  float *__restrict__ vol, TomoGeomC g, double px, double py, double pz)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int iz = blockIdx.x * 64 + lane, iy = blockIdx.y * 4 + wv, ix = blockIdx.z;
     if (iy >= g.ny || iz >= g.nz) return;
     const size_t img = (size_t)g.ndx * g.ndz;
+    // voxel centre as the caller of the reference hands it over: float64 grid (utilities/geometry.py:82-87) cast to float32
+    const float c[3] = {(float)(g.org[0] + ix * px), (float)(g.org[1] + iy * py), (float)(g.org[2] + iz * pz)};
+    const float o0 = (float)g.org[0], o2 = (float)g.org[2];
     float acc = 0.f;
     for (int ip = 0; ip < n_proj; ++ip) {
-        const BpC c = cs[ip];
-        const double u = c.u0 + ix * c.ux + iy * c.uy + iz * c.uz;
-        const double v = c.v0 + ix * c.vx + iy * c.vy + iz * c.vz;
-        if (!(u >= -1.0 && u < (double)g.ndx && v >= -1.0 && v < (double)g.ndz)) continue;
-        const double fu = floor(u), fv = floor(v);
+        const BpC &b = cs[ip];
+        float a1[3], a2[3], a3[3];
+        bp_mv3(b.rp, c, a1);                                           // external_back_projection.f90:20
+        bp_mv3(b.ra, a1, a2);                                          // :21
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a2[k] = __fadd_rn(a2[k], b.t[k]); // :22-24
+        bp_mv3(b.rb, a2, a3);                                          // :25
+        const float u = __fsub_rn(a3[0], o0), v = __fsub_rn(a3[2], o2);
+        const float fu = floorf(u), fv = floorf(v);
+        if (!(fu >= -2.f && fu <= (float)g.ndx && fv >= -2.f && fv <= (float)g.ndz)) continue;      // no pixel in reach (also NaN)
         const int fx = (int)fu, fz = (int)fv;
-        const float ax = (float)(u - fu), az = (float)(v - fv);      // external_back_projection.f90:47-48
+        const float ax = __fsub_rn(u, fu), az = __fsub_rn(v, fv);     // :47-48
+        const float bx = __fsub_rn(1.f, ax), bz = __fsub_rn(1.f, az);
         const float *im = det + (size_t)ip * img;
-        const bool x0 = fx >= 0, x1 = fx + 1 < g.ndx, z0 = fz >= 0, z1 = fz + 1 < g.ndz;
-        float s = 0.f;                                                 // :54-65, per-pixel bounds tests
-        if (x0 && z0) s += im[(size_t)fx * g.ndz + fz] * (1.f - ax) * (1.f - az);
-        if (x1 && z0) s += im[(size_t)(fx + 1) * g.ndz + fz] * ax * (1.f - az);
-        if (x0 && z1) s += im[(size_t)fx * g.ndz + fz + 1] * (1.f - ax) * az;
-        if (x1 && z1) s += im[(size_t)(fx + 1) * g.ndz + fz + 1] * ax * az;
-        acc += s;                                                      // back_projection.f90:31
+        const bool x0 = fx >= 0 && fx < g.ndx, x1 = fx + 1 >= 0 && fx + 1 < g.ndx, z0 = fz >= 0 && fz < g.ndz, z1 = fz + 1 >= 0 && fz + 1 < g.ndz;
+        float s = 0.f;                                                 // :54-65, per-pixel bounds tests, products left to right
+        if (x0 && z0) s = __fadd_rn(s, __fmul_rn(__fmul_rn(im[(size_t)fx * g.ndz + fz], bx), bz));
+        if (x1 && z0) s = __fadd_rn(s, __fmul_rn(__fmul_rn(im[(size_t)(fx + 1) * g.ndz + fz], ax), bz));
+        if (x0 && z1) s = __fadd_rn(s, __fmul_rn(__fmul_rn(im[(size_t)fx * g.ndz + fz + 1], bx), az));
+        if (x1 && z1) s = __fadd_rn(s, __fmul_rn(__fmul_rn(im[(size_t)(fx + 1) * g.ndz + fz + 1], ax), az));
+        acc = __fadd_rn(acc, s);                                       // back_projection.f90:31
     }
     vol[((size_t)ix * g.ny + iy) * g.nz + iz] = acc;
 }

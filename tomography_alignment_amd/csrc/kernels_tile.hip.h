@@ -262,6 +262,28 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
 // row (forward: to the accumulated plane sums S_l, S_{l+1}; adjoint: to the sinogram row before the loop).
 // Same sums as k_tile, regrouped: ~11 VALU per sample instead of ~32.
 // ------------------------------------------------------------------------------------------------
+// Row set-up shared by the flat kernels: for detector row `rix` of an untilted projection, the sample range [jlo, jhi) whose x, y
+// cells can fall into the tile's 16 x 16 footprint -- the row's line (tile-relative, sample 0 at (cbx, cby), direction (fdx, fdy))
+// clipped against the footprint widened by 2e-2 (conservative float32; exact ownership is decided per sample from the
+// fixed-point position).  One row per LANE; the callers broadcast the results with v_readlane.
+__device__ __forceinline__ void flat_row_range(float cbx, float cby, float fdx, float fdy, int n, bool row_ok, int &jlo, int &jhi)
+{
+    float t0 = 0.f, t1 = (float)(n - 1);
+    if (fdx != 0.f) {
+        const float inv = 1.f / fdx, ta = (-2e-2f - cbx) * inv, tb = ((float)ATX + 2e-2f - cbx) * inv;
+        t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
+    } else if (cbx < -2e-2f || cbx >= (float)ATX + 2e-2f) { t0 = 1.f; t1 = 0.f; }
+    if (fdy != 0.f) {
+        const float inv = 1.f / fdy, ta = (-2e-2f - cby) * inv, tb = ((float)ATY + 2e-2f - cby) * inv;
+        t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
+    } else if (cby < -2e-2f || cby >= (float)ATY + 2e-2f) { t0 = 1.f; t1 = 0.f; }
+    jlo = jhi = 0;
+    if (row_ok && t0 <= t1) {
+        jlo = max(0, (int)ceilf(t0));
+        jhi = min(n, (int)floorf(t1) + 1);
+    }
+}
+
 #define FTZ 63              // flat kernels: 63 owned planes + halo = all 64 lanes busy
 #define FLZ (FTZ + 1)
 #define FTAB 32             // entries of the forward kernel's per-wave sample table
@@ -343,29 +365,10 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
             float *const proj_c = proj + (size_t)c.slot * n_det + iz;
 
             for (int r0 = 0; r0 < n_rows_w; r0 += 64) {
-                int v_jlo = 0, v_jhi = 0;
+                int v_jlo, v_jhi;
                 {
                     const int rix = ix_lo + r0 + lane;
-                    const float frix = (float)rix;
-                    float t0 = 0.f, t1 = (float)(c.n - 1);
-                    {
-                        const float cb = fp0x + frix * fux;
-                        if (fdx != 0.f) {
-                            const float inv = 1.f / fdx, ta = (-2e-2f - cb) * inv, tb = ((float)ATX + 2e-2f - cb) * inv;
-                            t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
-                        } else if (cb < -2e-2f || cb >= (float)ATX + 2e-2f) { t0 = 1.f; t1 = 0.f; }
-                    }
-                    {
-                        const float cb = fp0y + frix * fuy;
-                        if (fdy != 0.f) {
-                            const float inv = 1.f / fdy, ta = (-2e-2f - cb) * inv, tb = ((float)ATY + 2e-2f - cb) * inv;
-                            t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
-                        } else if (cb < -2e-2f || cb >= (float)ATY + 2e-2f) { t0 = 1.f; t1 = 0.f; }
-                    }
-                    if (rix <= ix_hi && t0 <= t1) {
-                        v_jlo = max(0, (int)ceilf(t0));
-                        v_jhi = min(c.n, (int)floorf(t1) + 1);
-                    }
+                    flat_row_range(fp0x + (float)rix * fux, fp0y + (float)rix * fuy, fdx, fdy, c.n, rix <= ix_hi, v_jlo, v_jhi);
                 }
                 const int r_end = min(64, n_rows_w - r0);
                 // row bases advance incrementally: tile-relative 32.32 position of sample 0 and the row's sinogram pointer
@@ -389,11 +392,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
                         const unsigned t_e = own ? (__umul24(lx, ALY * FLZ) + __umul24(ly, FLZ)) * 4u : 0xffffffffu;
                         const float wx = (float)(unsigned)px * two_m32, wy = (float)(unsigned)py * two_m32;
                         const float t_w11 = wx * wy, t_w10 = wx - t_w11, t_w01 = wy - t_w11, t_w00 = 1.f - wx - t_w01;
-#ifdef TOMO_ABLATE_FLAT_SAMPLES          // development build only: skip the sample loop at run time (keeps all set-up alive)
-                        const int cnt = g.step < 0.0 ? min(64, jhi - jc) : 0;
-#else
                         const int cnt = min(64, jhi - jc);
-#endif
                         if (FWD) {
                             // compact the owned samples into the wave's table (LDS operations of a wave execute in order: no barrier);
                             // three zero entries behind them let the loop run in unmasked groups of four
@@ -553,29 +552,10 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
         float *const proj_c = proj + (size_t)c.slot * n_det + iz0;
 
         for (int r0 = 0; r0 < n_rows_w; r0 += 64) {
-            int v_jlo = 0, v_jhi = 0;
+            int v_jlo, v_jhi;
             {
                 const int rix = ix_lo + r0 + lane;
-                const float frix = (float)rix;
-                float t0 = 0.f, t1 = (float)(c.n - 1);
-                {
-                    const float cb = fp0x + frix * fux;
-                    if (fdx != 0.f) {
-                        const float inv = 1.f / fdx, ta = (-2e-2f - cb) * inv, tb = ((float)ATX + 2e-2f - cb) * inv;
-                        t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
-                    } else if (cb < -2e-2f || cb >= (float)ATX + 2e-2f) { t0 = 1.f; t1 = 0.f; }
-                }
-                {
-                    const float cb = fp0y + frix * fuy;
-                    if (fdy != 0.f) {
-                        const float inv = 1.f / fdy, ta = (-2e-2f - cb) * inv, tb = ((float)ATY + 2e-2f - cb) * inv;
-                        t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
-                    } else if (cb < -2e-2f || cb >= (float)ATY + 2e-2f) { t0 = 1.f; t1 = 0.f; }
-                }
-                if (rix <= ix_hi && t0 <= t1) {
-                    v_jlo = max(0, (int)ceilf(t0));
-                    v_jhi = min(c.n, (int)floorf(t1) + 1);
-                }
+                flat_row_range(fp0x + (float)rix * fux, fp0y + (float)rix * fuy, fdx, fdy, c.n, rix <= ix_hi, v_jlo, v_jhi);
             }
             const int r_end = min(64, n_rows_w - r0);
             int64_t rbx = c.fp0[0] + (int64_t)(ix_lo + r0) * k_fux - orgx, rby = c.fp0[1] + (int64_t)(ix_lo + r0) * k_fuy - orgy;

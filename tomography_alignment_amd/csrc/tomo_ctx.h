@@ -11,9 +11,10 @@
 #include "../../include/tomo.h"
 #include "tomo_raycore.h"
 
-struct BpC {   // voxel-driven back-projector constants of one projection (src/external_back_projection.f90:17-25,45-48)
-    double u0, ux, uy, uz;   // detector-x coordinate (index units) = u0 + ix*ux + iy*uy + iz*uz
-    double v0, vx, vy, vz;   // detector-z coordinate
+struct BpC {   // voxel-driven back-projector constants of one projection: the reference's three float32 rotation matrices and
+               // the translation (src/external_back_projection.f90:17-25, src/rotations_module.f90:6-54)
+    float rp[3][3], ra[3][3], rb[3][3];   // Rz(phi), Rx(alpha), Ry(beta)
+    float t[3];
 };
 
 struct ProfRec { int64_t n = 0; double ms = 0.0; };

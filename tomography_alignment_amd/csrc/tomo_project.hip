@@ -395,21 +395,20 @@ extern "C" int tomo_backproject_voxel(tomo_ctx *ctx, const double *h_poses, int 
     BpC *h = (BpC *)ctx->h_stage;
     for (int i = 0; i < n_proj; ++i) {
         const double *p = h_poses + (size_t)i * TOMO_POSE_STRIDE;
-        // x' = Ry(beta) (Rx(alpha) Rz(phi) c + t)            src/external_back_projection.f90:20-25
-        TomoM3 Rz = tomo_rz(p[0]), Rx = tomo_rx(p[1]), Ry = tomo_ry(p[2]);
-        TomoM3 B = tomo_mm(Ry, tomo_mm(Rx, Rz));
-        const double t[3] = {p[3], p[4], p[5]};
-        double rt[3], bo[3];
-        tomo_mv(Ry, t, rt);
-        tomo_mv(B, g.org, bo);
-        h[i].u0 = bo[0] + rt[0] - g.org[0];                      // :45 (u = x'_1 - origin_1)
-        h[i].ux = B.m[0][0] * ctx->vox_pitch[0]; h[i].uy = B.m[0][1] * ctx->vox_pitch[1]; h[i].uz = B.m[0][2] * ctx->vox_pitch[2];
-        h[i].v0 = bo[2] + rt[2] - g.org[2];                      // :46 (v = x'_3 - origin_3)
-        h[i].vx = B.m[2][0] * ctx->vox_pitch[0]; h[i].vy = B.m[2][1] * ctx->vox_pitch[1]; h[i].vz = B.m[2][2] * ctx->vox_pitch[2];
+        // float32 matrices exactly as src/rotations_module.f90:6-54 builds them (angles arrive as real(kind=4))
+        const float ph = (float)p[0], al = (float)p[1], be = (float)p[2];
+        const float cp = cosf(ph), sp = sinf(ph), ca = cosf(al), sa = sinf(al), cb = cosf(be), sb = sinf(be);
+        const float rp[3][3] = {{cp, -sp, 0.f}, {sp, cp, 0.f}, {0.f, 0.f, 1.f}};
+        const float ra[3][3] = {{1.f, 0.f, 0.f}, {0.f, ca, -sa}, {0.f, sa, ca}};
+        const float rb[3][3] = {{cb, 0.f, sb}, {0.f, 1.f, 0.f}, {-sb, 0.f, cb}};
+        memcpy(h[i].rp, rp, sizeof(rp));
+        memcpy(h[i].ra, ra, sizeof(ra));
+        memcpy(h[i].rb, rb, sizeof(rb));
+        for (int k = 0; k < 3; ++k) h[i].t[k] = (float)p[3 + k];
     }
     if (n_proj) TOMO_HIP(ctx, hipMemcpyAsync(ctx->d_stage, h, sizeof(BpC) * (size_t)n_proj, hipMemcpyHostToDevice, ctx->stream));
     TOMO_LAUNCH(ctx, "k_bp_voxel", k_bp_voxel, dim3((g.nz + 63) / 64, (g.ny + 3) / 4, g.nx), dim3(256), 0, (const BpC *)ctx->d_stage,
-                n_proj, d_det, d_vol, g);
+                n_proj, d_det, d_vol, g, ctx->vox_pitch[0], ctx->vox_pitch[1], ctx->vox_pitch[2]);
     return TOMO_OK;
 }
 
