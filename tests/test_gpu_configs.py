@@ -66,7 +66,7 @@ def test_config1_generate_data_and_sirt_128(capsys):
         # tests/test_oracle_golden.py::test_sirt_sensitivity_to_operator_rounding measures the ORACLE's own 10th iterate moving
         # by 5x (rel-max) / 2.6x (rel-L2) an operator perturbation of that size.  So 10 iterations are held to 1e-5 in rel-L2
         # (the whole volume) and in rms_error (a norm ratio), and to 2e-5 = 5 x 2e-6 x 2 in rel-max (the single worst voxel).
-        assert v[1] < TOL and v[0] < 2e-5 and v[2] < TOL, (tag, v)
+        assert v[1] < TOL and v[0] < TOL and v[2] < TOL, (tag, v)          # measured: rel-max 2-7e-7, rms_error 5e-6
 
 
 @pytest.fixture(scope="module")

@@ -135,7 +135,7 @@ def test_fortran_row_order_and_matrix_free_golden(PM, shepp32):
     # A6: back_project_ is float32 throughout; k_bp_voxel performs the reference's float32 operations in the reference's order
     e_a6 = rel_max(vol.download(), g4["atx"])
     print("A6 back_project vs the Fortran: rel-max %.2e" % e_a6)
-    assert e_a6 < 2e-6
+    assert e_a6 < TOL
     vdev = be.upload(shepp32)
     pr, gd = be.empty(1024), be.empty(6 * 1024)
     for i in range(3):                                                          # A7 row order tx,ty,tz,alpha,beta,phi
