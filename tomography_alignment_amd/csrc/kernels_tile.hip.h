@@ -600,27 +600,51 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
                     // an entry's five readlanes serve every image; (q[0], q[FLZ]) arrive as a register pair from one
                     // ds_read2st64 and the weights as SGPR pairs: two packed FMAs per sample and image.  Which images take part
                     // is decided outside the loop (an all-zero or out-of-range image is skipped).
-#define FZ_ENTRY(T, J)                                                                                                      \
-                        const unsigned T##e = (unsigned)__builtin_amdgcn_readlane(c_e, (J)) + lane4;                        \
-                        const f32x2 T##0 = {__int_as_float(__builtin_amdgcn_readlane(c_w00, (J))), __int_as_float(__builtin_amdgcn_readlane(c_w01, (J)))}; \
-                        const f32x2 T##1 = {__int_as_float(__builtin_amdgcn_readlane(c_w10, (J))), __int_as_float(__builtin_amdgcn_readlane(c_w11, (J)))};
-#define FZ_READ(T, K)                                                                                                       \
-                            const float *T##q = (const float *)((const char *)&img[0][0] + (T##e + (unsigned)(K) * (unsigned)(ALX * ALY * FLZ * 4))); \
-                            const f32x2 T##v0 = {T##q[0], T##q[FLZ]}, T##v1 = {T##q[ALY * FLZ], T##q[ALY * FLZ + FLZ]};
+                    // SOFTWARE-PIPELINED (round 2): the reads of entry jj + 1 are issued before entry jj's values are used.  The
+                    // one-entry-per-trip loop drained the LDS queue (s_waitcnt lgkmcnt(0)) before its last FMA, so every entry cost
+                    // a wave a full LDS round trip, and with 4 waves per SIMD the kernel sat at 56 % LDS / ~30 % VALU utilisation:
+                    // latency-bound.  Entries past n_own exist (ds_permute leaves 0 in lanes nobody wrote: address 0, weights 0), so
+                    // the look-ahead needs no guard.  The second image lies 73 984 B behind the first -- beyond the 16-bit DS offset
+                    // field: its base is formed once per entry and kept opaque, or the compiler folds the constant into four
+                    // separate ds_read_b32 addresses instead of two ds_read2st64_b32.
+                    {
+                        int r_e = c_e, r_w00 = c_w00, r_w01 = c_w01, r_w10 = c_w10, r_w11 = c_w11;
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r_e), "+v"(r_w00), "+v"(r_w01), "+v"(r_w10), "+v"(r_w11));   // the permutes have landed: no waits on them inside the loop
+#define FZ_LOAD(T, J, K0, K1)                                                                                               \
+                        {                                                                                                   \
+                            const unsigned e_ = (unsigned)__builtin_amdgcn_readlane(r_e, (J)) + lane4;                      \
+                            _Pragma("unroll") for (int k = (K0); k < (K1); ++k) {                                           \
+                                unsigned a_ = e_ + (unsigned)k * (unsigned)(ALX * ALY * FLZ * 4);                           \
+                                if (k) asm volatile("" : "+v"(a_));                                                         \
+                                const float *q_ = (const float *)((const char *)&img[0][0] + a_);                           \
+                                T##v0[k] = (f32x2){q_[0], q_[FLZ]};                                                         \
+                                T##v1[k] = (f32x2){q_[ALY * FLZ], q_[ALY * FLZ + FLZ]};                                     \
+                            }                                                                                               \
+                        }
+#define FZ_USE(T, J, K0, K1)                                                                                                \
+                        {                                                                                                   \
+                            const f32x2 w0_ = {__int_as_float(__builtin_amdgcn_readlane(r_w00, (J))), __int_as_float(__builtin_amdgcn_readlane(r_w01, (J)))}; \
+                            const f32x2 w1_ = {__int_as_float(__builtin_amdgcn_readlane(r_w10, (J))), __int_as_float(__builtin_amdgcn_readlane(r_w11, (J)))}; \
+                            _Pragma("unroll") for (int k = (K0); k < (K1); ++k) { Sa[k] += w0_ * T##v0[k]; Sb[k] += w1_ * T##v1[k]; } \
+                        }
 #define FZ_SAMPLE_LOOP(K0, K1)                                                                                              \
-                    for (int jj = 0; jj < n_own; ++jj) { /* one entry per trip: pairs measured the same, fours 6 % slower */ \
-                        FZ_ENTRY(s0_, jj)                                                                                   \
-                        _Pragma("unroll") for (int k = (K0); k < (K1); ++k) {                                               \
-                            FZ_READ(s0_, k)                                                                                 \
-                            Sa[k] += s0_0 * s0_v0; Sb[k] += s0_1 * s0_v1;                                                   \
-                        }                                                                                                   \
-                    }
-                    if (NZT == 2 && zuse[0] && zuse[NZT - 1]) { FZ_SAMPLE_LOOP(0, NZT) }
-                    else if (zuse[0]) { FZ_SAMPLE_LOOP(0, 1) }
-                    else { FZ_SAMPLE_LOOP(NZT - 1, NZT) }
+                        {                                                                                                   \
+                            f32x2 A_v0[NZT], A_v1[NZT], B_v0[NZT], B_v1[NZT];                                               \
+                            FZ_LOAD(A_, 0, K0, K1)                                                                          \
+                            for (int jj = 0; jj < n_own; jj += 2) {                                                         \
+                                FZ_LOAD(B_, jj + 1, K0, K1)                                                                 \
+                                FZ_USE(A_, jj, K0, K1)                                                                      \
+                                FZ_LOAD(A_, jj + 2, K0, K1)                                                                 \
+                                FZ_USE(B_, jj + 1, K0, K1)                                                                  \
+                            }                                                                                               \
+                        }
+                        if (NZT == 2 && zuse[0] && zuse[NZT - 1]) { FZ_SAMPLE_LOOP(0, NZT) }
+                        else if (zuse[0]) { FZ_SAMPLE_LOOP(0, 1) }
+                        else { FZ_SAMPLE_LOOP(NZT - 1, NZT) }
 #undef FZ_SAMPLE_LOOP
-#undef FZ_READ
-#undef FZ_ENTRY
+#undef FZ_USE
+#undef FZ_LOAD
+                    }
 #pragma unroll
                     for (int k = 0; k < NZT; ++k) {
                         const f32x2 St = Sa[k] + Sb[k];
@@ -674,7 +698,7 @@ struct GfC {
 };
 
 template <int NJ>      // samples per row that can reach a column: 3 for step >= 0.95 voxel, 6 for step >= 0.475
-__global__ __launch_bounds__(GWAVES * 64) void k_adj_gather_flat(const GfC *__restrict__ cs, int n_proj, const float *__restrict__ proj,
+__global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *__restrict__ cs, int n_proj, const float *__restrict__ proj,
                                                                  float *__restrict__ vol, TomoGeomC g, int xs, int xe, int patched)
 {
     __shared__ float rows[GWAVES][GROWS * GPITCH];
