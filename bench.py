@@ -13,9 +13,9 @@ angle shards (RCCL over xGMI; strong scaling: the 1024 angles are split across t
 Inputs are resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line ("Measurement"):
-  roofline     the projector kernel that takes most of a step: counted work per launch (wave-instructions by unit,
-               LDS bytes, HBM bytes -- rocprofv3 PMC passes of THIS command, committed under profiles/) / mean launch time
-               measured live (HIP events on the kernel's own stream inside the timed region) against the unit's peak
+  roofline     the projector kernel that takes most of a step: work counted per launch by unit (VALU execution cycles, LDS-array
+               cycles, HBM bytes -- rocprofv3 PMC passes of THIS command, committed under profiles/) / mean launch time
+               measured live (HIP events on the kernel's own stream inside the timed region) against what the chip offers
                (MI355X_MICROARCH.md); `bound` is the unit with the highest utilisation.  The algorithmic-HBM figure of
                SURVEY 8d (volume re-read per angle) is kept as `hbm_algorithmic` -- it exceeds the HBM peak for the LDS-tile
                kernels, which read the volume from HBM once per CALL, and is therefore not the roofline.
@@ -373,10 +373,12 @@ def make_roofline(name, ms_per_step, launches_per_step, alg_bytes_per_pass, key)
     if pmc is not None:
         util["hbm"] = (pmc / t / 1e9, HBM_PEAK_GBS, "GB/s")
     if sq is not None:
-        if sq.get("SQ_INSTS_VALU"):
-            util["valu_issue"] = (sq["SQ_INSTS_VALU"] / t / 1e9, VALU_PEAK_GINSTR, "Ginstr/s")
-        if sq.get("lds_bytes"):
-            util["lds"] = (sq["lds_bytes"] / t / 1e9, LDS_PEAK_GBS, "GB/s")
+        # unit-busy cycles counted by the SQ for this launch (MI355X_MICROARCH: SQ_LDS_IDX_ACTIVE = all LDS-array cycles;
+        # SQ_ACTIVE_INST_VALU counts quad-cycles of VALU execution per SIMD) against the cycles the chip has in the live time
+        if sq.get("SQ_ACTIVE_INST_VALU"):
+            util["valu"] = (4.0 * sq["SQ_ACTIVE_INST_VALU"] / t / 1e9, N_CU * 4 * CLK_GHZ, "G SIMD-cycles/s")
+        if sq.get("SQ_LDS_IDX_ACTIVE"):
+            util["lds"] = (sq["SQ_LDS_IDX_ACTIVE"] / t / 1e9, N_CU * CLK_GHZ, "G LDS-cycles/s")
     if not util:
         # no counters for this exact workload: fall back to the algorithmic-HBM figure, capped reading left to the consumer
         r.update({"bound": "hbm", "achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 4),
@@ -386,10 +388,20 @@ def make_roofline(name, ms_per_step, launches_per_step, alg_bytes_per_pass, key)
     ach, peak, unit = util[bound]
     r.update({"bound": bound, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": unit, "frac": round(ach / peak, 4),
               "utilisation": {k: {"achieved": round(v[0], 1), "peak": round(v[1], 1), "unit": v[2], "frac": round(v[0] / v[1], 4)} for k, v in util.items()}})
-    if "valu_issue" in util:
-        r["utilisation"]["valu_issue"]["frac_of_measured_ceiling"] = round(util["valu_issue"][0] / VALU_MEASURED_GINSTR, 4)
-    if "lds" in util:
-        r["utilisation"]["lds"]["frac_of_measured_ceiling"] = round(util["lds"][0] / (LDS_MEASURED_GINSTR2 * 512.0), 4)
+    if sq is not None:
+        # the same launch in instruction counts (secondary): wave-instructions per second by unit, and the LDS bytes they move
+        # (SQ_INSTS_LDS x the bytes of this kernel's LDS instruction, tools/summarise_sq.py) against the spec / measured ceilings
+        info = {}
+        if sq.get("SQ_INSTS_VALU"):
+            info["valu_Ginstr_per_s"] = round(sq["SQ_INSTS_VALU"] / t / 1e9, 1)
+            info["valu_frac_of_simd32_issue_peak"] = round(sq["SQ_INSTS_VALU"] / t / 1e9 / VALU_PEAK_GINSTR, 4)
+            info["valu_frac_of_measured_fma_ceiling"] = round(sq["SQ_INSTS_VALU"] / t / 1e9 / VALU_MEASURED_GINSTR, 4)
+        if sq.get("lds_bytes"):
+            info["lds_GBps"] = round(sq["lds_bytes"] / t / 1e9, 1)
+            info["lds_frac_of_peak_bandwidth"] = round(sq["lds_bytes"] / t / 1e9 / LDS_PEAK_GBS, 4)
+        if sq.get("SQ_INSTS_SALU"):
+            info["salu_Ginstr_per_s"] = round(sq["SQ_INSTS_SALU"] / t / 1e9, 1)
+        r["instruction_rates"] = info
     return r
 
 

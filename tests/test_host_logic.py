@@ -325,13 +325,16 @@ def test_bench_launcher_and_roofline_logic_without_a_gpu(tmp_path, monkeypatch):
     import bench
     prof = tmp_path / "profiles"
     prof.mkdir()
-    json.dump({"key": "K", "source": "t", "kernels": {"k_fwd_tile_flat": {"SQ_INSTS_VALU": 2.0e11, "SQ_INSTS_LDS": 6.0e10, "lds_bytes": 6.0e10 * 512}}}, open(prof / "sq_counters.json", "w"))
+    json.dump({"key": "K", "source": "t", "kernels": {"k_fwd_tile_flat": {"SQ_INSTS_VALU": 2.0e11, "SQ_INSTS_LDS": 6.0e10, "lds_bytes": 6.0e10 * 512,
+                                                                          "SQ_ACTIVE_INST_VALU": 1.5e11, "SQ_LDS_IDX_ACTIVE": 2.4e11}}},
+              open(prof / "sq_counters.json", "w"))
     json.dump({"key": "K", "source": "t", "kernels": {"k_fwd_tile_flat": {"hbm_bytes_per_launch": 4.0e11}}}, open(prof / "pmc_traffic.json", "w"))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     r = bench.make_roofline("k_fwd_tile_flat", 500.0, 1.0, 4.4e12, "K")
-    assert r["bound"] == "lds" and r["unit"] == "GB/s" and 0.0 < r["frac"] <= 1.0
-    assert abs(r["frac"] - 6.0e10 * 512 / 0.5 / 1e9 / bench.LDS_PEAK_GBS) < 1e-3
-    assert r["utilisation"]["valu_issue"]["frac"] < r["frac"] and r["utilisation"]["hbm"]["frac"] < 0.2
+    # LDS-array cycles 2.4e11 / 0.5 s = 480 G/s of the 614.4 G/s (256 CUs x 2.4 GHz) = 0.78; VALU 4 x 1.5e11 / 0.5 = 1200 of 2457.6 = 0.49
+    assert r["bound"] == "lds" and 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - 2.4e11 / 0.5 / 1e9 / 614.4) < 1e-3
+    assert abs(r["utilisation"]["valu"]["frac"] - 4 * 1.5e11 / 0.5 / 1e9 / 2457.6) < 1e-3 and r["utilisation"]["hbm"]["frac"] < 0.2
     assert r["hbm_algorithmic"]["frac_of_hbm_peak"] > 1.0 and r["traffic"] == 4.0e11          # kept, labelled, not the roofline
+    assert r["instruction_rates"]["lds_GBps"] > 0
     r2 = bench.make_roofline("k_fwd_tile_flat", 500.0, 1.0, 4.4e12, "other-workload")
     assert r2["bound"] == "hbm" and r2["counters"] is None and "no committed PMC counters" in r2["note"]

@@ -5,17 +5,25 @@
 // ------------------------------------------------------------------------------------------------
 // wave helpers (64 lanes)
 // ------------------------------------------------------------------------------------------------
+// Wave-wide integer min / max, the result in every lane (wave-uniform): quad and row butterflies with DPP (full-rate VALU:
+// quad_perm xor 1, xor 2, row_half_mirror, row_mirror make each row of 16 lanes uniform), then the four rows meet on the scalar
+// unit.  No LDS traffic -- the __shfl_xor form costs six ds_bpermute round trips, and the gather adjoint takes two of these per
+// projection and wave.  ALL 64 LANES MUST BE ACTIVE (v_readlane reads lanes 0 / 16 / 32 / 48 whatever EXEC says).
 __device__ __forceinline__ int wave_min_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));    // row_half_mirror
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));    // row_mirror
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ int wave_max_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ double wave_sum_d(double v)
 {

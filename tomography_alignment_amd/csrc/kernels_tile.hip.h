@@ -677,7 +677,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
 //      z chunk of the tile: the four waves of a work-group (four z chunks) each compute it for every fourth projection and
 //      share it through a triple-buffered LDS table, one barrier per four projections;
 //   2. lane = PLANE: the z-lerped sinogram rows the tile can touch (<= 14) are loaded once (coalesced) into wave-private LDS
-//      rows (pitch 65 dwords, so that lanes reading different rows of one plane hit different banks);
+//      rows (pitch 68 dwords: 16-byte aligned plane quads, lanes reading different rows hit different bank quads);
 //   3. lane = COLUMN again, 64 plane accumulators per lane (statically indexed registers): per plane 3 ds_read_b32 at
 //      row(lane) + immediate plane offset and 3 FMA with the lane's own W0..W2 -- no broadcasts, no address arithmetic.
 // Same sums as k_tile_flat<false> (which needs 4 ds_add_u32 per sample and lane), regrouped by voxel instead of by sample.
@@ -685,7 +685,8 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
 #define GTX 8
 #define GTY 8
 #define GROWS 14          // rows a tile can touch: i0 spreads over <= 7 (|m00| + |m01|) <= 10.2 -> 11 values, + 3
-#define GPITCH 65          // LDS row pitch in dwords: rows r, r+1, ... of one plane fall in different banks
+#define GPITCH 68          // LDS row pitch in dwords: a multiple of 4, so that a row's plane quads (p .. p+3) are 16-byte aligned for ds_read_b128; rows r, r+1, ...
+                           // of one plane quad fall in different bank quads (4 r + p mod 64)
 #define GWAVES 4
 #define GPX 8              // (x, y) tile patch that one XCD's resident work-groups cover together
 #define GPY 12
@@ -701,7 +702,7 @@ template <int NJ>      // samples per row that can reach a column: 3 for step >=
 __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *__restrict__ cs, int n_proj, const float *__restrict__ proj,
                                                                  float *__restrict__ vol, TomoGeomC g, int xs, int xe, int patched)
 {
-    __shared__ float rows[GWAVES][GROWS * GPITCH];
+    __shared__ __attribute__((aligned(16))) float rows[GWAVES][GROWS * GPITCH];
     __shared__ float4 wtab[3][GWAVES][64];          // [group mod 3][projection of the group][column] = (i0, W0, W1, W2)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -831,12 +832,17 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
             //         written by this same wave (LDS operations of a wave execute in order), no other wave touches them.
             if (hit) {
                 const int slot0 = min(max(i0 - ix_lo, 0), GROWS - 3);       // <= nrows - 3 by construction; clamped for safety
-                const float *q = wrows + slot0 * GPITCH;
+                // plane QUADS with ds_read_b128 (round 2): 256 B/clk where ds_read_b32 moves 128 B/clk -- the kernel was LDS-bound
+                // (SQ_LDS_IDX_ACTIVE = 0.79 of its cycles) on 3 x 64 dword reads per projection
+                const float4 *q = (const float4 *)__builtin_assume_aligned(wrows + slot0 * GPITCH, 16);
 #pragma unroll
-                for (int p = 0; p < 64; ++p) {
-                    acc[p] = fmaf(W0, q[p], acc[p]);
-                    acc[p] = fmaf(W1, q[GPITCH + p], acc[p]);
-                    acc[p] = fmaf(W2, q[2 * GPITCH + p], acc[p]);
+                for (int p = 0; p < 64; p += 4) {
+                    const float4 r0 = q[p / 4], r1 = q[(GPITCH + p) / 4], r2 = q[(2 * GPITCH + p) / 4];
+                    acc[p] = fmaf(W2, r2.x, fmaf(W1, r1.x, fmaf(W0, r0.x, acc[p])));
+                    acc[p + 1] = fmaf(W2, r2.y, fmaf(W1, r1.y, fmaf(W0, r0.y, acc[p + 1])));
+                    acc[p + 2] = fmaf(W2, r2.z, fmaf(W1, r1.z, fmaf(W0, r0.z, acc[p + 2])));
+                    acc[p + 3] = fmaf(W2, r2.w, fmaf(W1, r1.w, fmaf(W0, r0.w, acc[p + 3])));
+                    __builtin_amdgcn_sched_barrier(0);                       // one quad of reads in flight per wave: 12 temporaries, not 192 (4 waves per SIMD hide the latency)
                 }
             }
         }
