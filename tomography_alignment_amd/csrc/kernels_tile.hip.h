@@ -736,6 +736,7 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
     const int X = x0 + (lane >> 3), Y = y0 + (lane & 7), Zl = z0 + lane;
     float *wrows = rows[wv];
     const size_t n_det = (size_t)g.ndx * g.ndz;
+    const uint32_t pitch4 = (uint32_t)g.ndz * 4u;                     // one projection's sinogram is < 4 GiB (host check)
     const float two_m32 = 2.3283064365386963e-10f;
     float acc[64];
 #pragma unroll
@@ -792,12 +793,14 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
         if (zlive) {                                                                                                       \
             const GfC &cn = cs[IPX];                                                                                       \
             const int iz0 = Zl - cn.zc;                                                                                    \
-            const float *srow = proj + (size_t)cn.slot * n_det;                                                            \
-            const float *p0 = srow + min(max(iz0, 0), g.ndz - 1), *p1 = srow + min(max(iz0 - 1, 0), g.ndz - 1);            \
+            const char *srow = (const char *)(proj + (size_t)cn.slot * n_det);                          /* wave-uniform */ \
+            /* one 32-bit byte offset per lane and plane shift, a wave-uniform 64-bit row base on the scalar unit: the loads */ \
+            /* take the saddr + voffset form (no 64-bit VALU add per load)                                                 */ \
+            const uint32_t o0 = (uint32_t)min(max(iz0, 0), g.ndz - 1) * 4u, o1 = (uint32_t)min(max(iz0 - 1, 0), g.ndz - 1) * 4u; \
             _Pragma("unroll") for (int r = 0; r < GROWS; ++r) {                                                            \
-                const size_t ro = (size_t)min(max(ix_lo_n + r, 0), g.ndx - 1) * g.ndz; /* wave-uniform */                  \
-                y0v[r] = p0[ro];                                                                                           \
-                y1v[r] = p1[ro];                                                                                           \
+                const char *rb = srow + (uint32_t)min(max(ix_lo_n + r, 0), g.ndx - 1) * pitch4; /* wave-uniform, 32-bit scalar math */ \
+                y0v[r] = *(const float *)(rb + o0);                                                                        \
+                y1v[r] = *(const float *)(rb + o1);                                                                        \
             }                                                                                                              \
         }                                                                                                                  \
     }
