@@ -384,6 +384,9 @@ def make_roofline(name, ms_per_step, launches_per_step, alg_bytes_per_pass, key)
         r.update({"bound": "hbm", "achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 4),
                   "note": "no committed PMC counters for workload key %s: algorithmic-HBM figure (may exceed 1 for the LDS-tile kernels)" % key})
         return r
+    # `valu` is AMD's VALUBusy: a wave64 VALU instruction is counted as one quad-cycle of its SIMD although the SIMD retires the
+    # simple integer ones faster (tools/issue_bench.hip: v_add_u32 one per 2 clk, v_fma_f32 one per 2.65), so a kernel made of those
+    # can read slightly above 1 (the tilted adjoint reads 1.04); `lds` and `hbm` are capped by 1.
     bound = max(util, key=lambda k: util[k][0] / util[k][1])
     ach, peak, unit = util[bound]
     r.update({"bound": bound, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": unit, "frac": round(ach / peak, 4),

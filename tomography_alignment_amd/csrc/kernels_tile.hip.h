@@ -56,12 +56,39 @@ __device__ __forceinline__ int cvt_round_i32(float x)
 // trilinear value with the lerps ordered y -> x -> z so that the (z, z+1) register pairs ds_read2_b32 returns feed the
 // packed ops directly: p00 = (v000, v001), p01 = (v010, v011), p10 = (v100, v101), p11 = (v110, v111)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) float lds_cfloat;
 __device__ __forceinline__ float trilerp_pairs(f32x2 p00, f32x2 p01, f32x2 p10, f32x2 p11, float wx, float wy, float wz)
 {
     const f32x2 c0 = p00 + wy * (p01 - p00);
     const f32x2 c1 = p10 + wy * (p11 - p10);
     const f32x2 e = c0 + wx * (c1 - c0);
     return fmaf(wz, e.y - e.x, e.x);
+}
+
+// v if the lane's bit is set in the wave-uniform mask m, else 0.  Written as the SGPR-pair form of v_cndmask_b32: the form that reads
+// VCC retires one per ~13 clk per SIMD on gfx950 against ~3 for this one (tools/issue_bench.hip, profiles/round2_issue_bench.log).
+__device__ __forceinline__ float select_lanes(float v, unsigned long long m)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
+    return r;
+}
+
+// b where the lane's bit is set in m, else a
+__device__ __forceinline__ float select_lanes2(float a, float b, unsigned long long m)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+    return r;
+}
+
+// per-lane 64-bit position + wave-uniform 64-bit step in one VALU instruction, kept opaque so that the low word (the fraction)
+// and the high word (the cell) are used as they come (the compiler otherwise re-forms base + scalar offset and adds the low
+// words a second time)
+__device__ __forceinline__ int64_t add64_vs(int64_t p, int64_t step)
+{
+    asm("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(p) : "s"(step));
+    return p;
 }
 
 // FWD = true : the LDS image holds the volume tile (+1 high-side halo, zeros outside the volume); owned samples are
@@ -79,7 +106,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
                                                          float weight_bound, int tile_x0)
 {
     __shared__ int acc[ALX * ALY * ALZ + 4];        // + pad: a masked-out lane may read one dword past the last row (its value is discarded)
-    const float *img = (const float *)acc;
+    const lds_cfloat *img3 = (const lds_cfloat *)acc;       // explicit LDS pointer: offsets made opaque below must still give ds_read
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int z0 = -1 + (int)blockIdx.x * ATZ, y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + ((int)blockIdx.z + tile_x0) * ATX;
@@ -198,46 +225,52 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
                                 const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32), lz = (unsigned)(pz >> 32);
                                 static_assert(ATX == ATY && (ATX & (ATX - 1)) == 0, "ownership test uses (lx | ly) < ATX");
                                 static_assert(ALY == 17 && ALZ == 64, "cell index is written with shifts");
-                                const bool own = (lx | ly) < (unsigned)ATX && lz < (unsigned)ATZ;
+                                const unsigned long long own = __builtin_amdgcn_ballot_w64((lx | ly) < (unsigned)ATX) & __builtin_amdgcn_ballot_w64(lz < (unsigned)ATZ);
                                 // Lanes that do not own the sample still read (and discard): from a cell clamped into the image whose LDS
                                 // bank is the one their own z would have -- lanes sit on consecutive z, so the 32 lanes of a bank group keep
                                 // 32 different banks.  (They used to read word 0: every such lane then hit bank 0 together with whichever
                                 // owner lane mapped there -- SQ_LDS_BANK_CONFLICT was 47 % of the kernel's LDS cycles, LDS 81 % busy.)
                                 const unsigned cx = min(lx, (unsigned)(ATX - 1)), cy = min(ly, (unsigned)(ATY - 1)), cz = lz & 63u;
-                                const unsigned e = (((cx << 4) + cx + cy) << 6) + cz;                  // (cx * ALY + cy) * ALZ + cz without a quarter-rate multiply
+                                const unsigned eb = (((cx << 4) + cx + cy) << 8) + (cz << 2);          // byte offset of cell (cx, cy, cz): (cx * ALY + cy) * ALZ + cz, no quarter-rate multiply
                                 const float wx = (float)(unsigned)px * two_m32, wy = (float)(unsigned)py * two_m32, wz = (float)(unsigned)pz * two_m32;
-                                const float *q = img + e;
+                                unsigned eb1 = eb + ALY * ALZ * 4;
+                                asm("" : "+v"(eb1));                      // one add for the x+1 face; its y+1 rows sit within ds_read2's offset range
+                                const lds_cfloat *q = (const lds_cfloat *)((const __attribute__((address_space(3))) char *)img3 + eb);
+                                const lds_cfloat *q1 = (const lds_cfloat *)((const __attribute__((address_space(3))) char *)img3 + eb1);
                                 const f32x2 p00 = {q[0], q[1]}, p01 = {q[ALZ], q[ALZ + 1]};
-                                const f32x2 p10 = {q[ALY * ALZ], q[ALY * ALZ + 1]}, p11 = {q[ALY * ALZ + ALZ], q[ALY * ALZ + ALZ + 1]};
-                                const float v = trilerp_pairs(p00, p01, p10, p11, wx, wy, wz);
-                                part += own ? v : 0.f;
-                                px += c.fd[0]; py += c.fd[1]; pz += c.fd[2];
-                            }
+                                const f32x2 p10 = {q1[0], q1[1]}, p11 = {q1[ALZ], q1[ALZ + 1]};
+                                part += select_lanes(trilerp_pairs(p00, p01, p10, p11, wx, wy, wz), own);
+                                px = add64_vs(px, c.fd[0]); py = add64_vs(py, c.fd[1]); pz = add64_vs(pz, c.fd[2]);
+                            }                                          // (two samples per trip, 8 reads in flight: measured no faster -- the loop is VALU-issue bound)
                             if (lane_ok) atomicAdd(pr, part);          // 64 consecutive floats per wave: the full-rate atomic shape
                         } else {
                             const float ys = (lane_ok ? *pr : 0.f) * scale;
                             // straight-line body: a lane that does not own the sample adds integer 0 to a cell clamped into the image on
                             // its own z bank (see the forward) -- no exec-mask switches between samples (two s_cbranch_execz per sample
                             // before: 1.52 -> 1.41 ms/angle at 1024^3)
+                            f32x2 ksc = {-two_m32, two_m32}, kof = {1.f, 0.f};
+                            asm("" : "+v"(kof));                        // held in a VGPR pair (else re-materialised per sample)
                             for (int jj = 0; jj < cnt; ++jj) {
                                 const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32), lz = (unsigned)(pz >> 32);
-                                const bool own = (lx | ly) < (unsigned)ATX && lz < (unsigned)ATZ;
-                                const float yo = own ? ys : 0.f;
+                                const float yo = select_lanes(ys, __builtin_amdgcn_ballot_w64((lx | ly) < (unsigned)ATX) & __builtin_amdgcn_ballot_w64(lz < (unsigned)ATZ));
                                 const unsigned cx = min(lx, (unsigned)(ATX - 1)), cy = min(ly, (unsigned)(ATY - 1)), cz = lz & 63u;
-                                const float wcx = (float)(unsigned)px * two_m32, wcy = (float)(unsigned)py * two_m32, wcz = (float)(unsigned)pz * two_m32;
-                                const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
-                                const float a0 = yo * wfx, a1 = yo * wcx;
-                                const float b00 = a0 * wfy, b01 = a0 * wcy, b10 = a1 * wfy, b11 = a1 * wcy;
+                                // (1 - w, w) per axis as one packed pair, products as packed multiplies: 3 + 7 packed instructions for what
+                                // were 6 + 14 scalar ones (same operations in the same order)
+                                const float fx = (float)(unsigned)px, fy = (float)(unsigned)py, fz = (float)(unsigned)pz;
+                                const f32x2 wxp = f32x2{fx, fx} * ksc + kof, wyp = f32x2{fy, fy} * ksc + kof, wzp = f32x2{fz, fz} * ksc + kof;
+                                const f32x2 a = yo * wxp;
+                                const f32x2 b0 = a.x * wyp, b1 = a.y * wyp;
+                                const f32x2 c00 = b0.x * wzp, c01 = b0.y * wzp, c10 = b1.x * wzp, c11 = b1.y * wzp;
                                 int *q = &acc[(((cx << 4) + cx + cy) << 6) + cz];
-                                atomicAdd(q, cvt_round_i32(b00 * wfz));
-                                atomicAdd(q + 1, cvt_round_i32(b00 * wcz));
-                                atomicAdd(q + ALZ, cvt_round_i32(b01 * wfz));
-                                atomicAdd(q + ALZ + 1, cvt_round_i32(b01 * wcz));
-                                atomicAdd(q + ALY * ALZ, cvt_round_i32(b10 * wfz));
-                                atomicAdd(q + ALY * ALZ + 1, cvt_round_i32(b10 * wcz));
-                                atomicAdd(q + ALY * ALZ + ALZ, cvt_round_i32(b11 * wfz));
-                                atomicAdd(q + ALY * ALZ + ALZ + 1, cvt_round_i32(b11 * wcz));
-                                px += c.fd[0]; py += c.fd[1]; pz += c.fd[2];
+                                atomicAdd(q, cvt_round_i32(c00.x));
+                                atomicAdd(q + 1, cvt_round_i32(c00.y));
+                                atomicAdd(q + ALZ, cvt_round_i32(c01.x));
+                                atomicAdd(q + ALZ + 1, cvt_round_i32(c01.y));
+                                atomicAdd(q + ALY * ALZ, cvt_round_i32(c10.x));
+                                atomicAdd(q + ALY * ALZ + 1, cvt_round_i32(c10.y));
+                                atomicAdd(q + ALY * ALZ + ALZ, cvt_round_i32(c11.x));
+                                atomicAdd(q + ALY * ALZ + ALZ + 1, cvt_round_i32(c11.y));
+                                px = add64_vs(px, c.fd[0]); py = add64_vs(py, c.fd[1]); pz = add64_vs(pz, c.fd[2]);
                             }
                         }
                     }
@@ -765,12 +798,13 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
                 _Pragma("unroll") for (int mth = 0; mth < NJ; ++mth) {                                                     \
                     const int hx = (int)(sx >> 32), hy = (int)(sy >> 32);                                                  \
                     const float fx = (float)(unsigned)sx * two_m32, fy = (float)(unsigned)sy * two_m32;                    \
-                    const float wx = hx == 0 ? 1.f - fx : (hx == -1 ? fx : 0.f); /* tent on [-1, 1) */                     \
-                    const float wy = hy == 0 ? 1.f - fy : (hy == -1 ? fy : 0.f);                                           \
-                    wsum += ((unsigned)(j0 + mth) < (unsigned)ct.n) ? wx * wy : 0.f;                                       \
+                    /* tent on [-1, 1); selects in the SGPR-mask form (select_lanes) */                                    \
+                    const float wx = select_lanes2(select_lanes(fx, __builtin_amdgcn_ballot_w64(hx == -1)), 1.f - fx, __builtin_amdgcn_ballot_w64(hx == 0)); \
+                    const float wy = select_lanes2(select_lanes(fy, __builtin_amdgcn_ballot_w64(hy == -1)), 1.f - fy, __builtin_amdgcn_ballot_w64(hy == 0)); \
+                    wsum += select_lanes(wx * wy, __builtin_amdgcn_ballot_w64((unsigned)(j0 + mth) < (unsigned)ct.n));     \
                     sx += ct.fdx; sy += ct.fdy;                                                                            \
                 }                                                                                                          \
-                W[k] = ((unsigned)(i0 + k) < (unsigned)g.ndx) ? wsum : 0.f;                                                \
+                W[k] = select_lanes(wsum, __builtin_amdgcn_ballot_w64((unsigned)(i0 + k) < (unsigned)g.ndx));              \
                 rx += ct.fux; ry += ct.fuy;                                                                                \
             }                                                                                                              \
             t4.x = __builtin_bit_cast(float, i0); t4.y = W[0]; t4.z = W[1]; t4.w = W[2];                                   \

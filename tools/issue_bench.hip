@@ -18,10 +18,13 @@
 #define R4(x) x x x x
 #define R16(x) R4(x) R4(x) R4(x) R4(x)
 
-enum Op { FMA, PK_FMA, ADD_U32, ADD64, READLANE, CVT, MUL_LO, MAD_U24, DPP_MOV, FLOOR, FRACT, CNDMASK, PERMUTE,
+enum Op { FMA, PK_FMA, ADD_U32, ADD64, READLANE, CVT, MUL_LO, MAD_U24, DPP_MOV, FLOOR, FRACT, CNDMASK, CNDMASK_IND, CNDMASK_SGPR, MUL_HI_I32, MUL_HI_U32, MIN_U32,
+          CVT_RPI, PK_MUL, LSHL_ADD, BFE_I32, CMP_LT, PERMUTE,
           DS_READ_B32, DS_READ2_B32, DS_READ2ST64, DS_READ_B64, DS_READ_B128, DS_ADD_U32, DS_ADD_U64, DS_ADD_F32, DS_WRITE_B32, N_OPS };
 static const char *op_name[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_add_u32", "v_add_co+v_addc (64-bit add)", "v_readlane_b32", "v_cvt_f32_u32",
                                      "v_mul_lo_u32", "v_mad_u32_u24", "v_mov_b32 dpp wave_shl:1", "v_floor_f32", "v_fract_f32", "v_cndmask_b32",
+                                     "v_cndmask_b32 (indep. dst, vcc set)", "v_cndmask_b32 (sgpr-pair mask)", "v_mul_hi_i32", "v_mul_hi_u32", "v_min_u32",
+                                     "v_cvt_rpi_i32_f32", "v_pk_mul_f32", "v_lshl_add_u32", "v_bfe_i32", "v_cmp_lt_u32 (to sgpr pair)",
                                      "ds_permute_b32", "ds_read_b32", "ds_read2_b32", "ds_read2st64_b32", "ds_read_b64", "ds_read_b128",
                                      "ds_add_u32", "ds_add_u64", "ds_add_f32", "ds_write_b32"};
 
@@ -40,6 +43,8 @@ __global__ __launch_bounds__(256) void k_issue(int iters, unsigned long long *cy
     unsigned u0 = lane, u1 = lane + 1, u2 = lane + 2, u3 = lane + 3;
     unsigned long long w0 = lane, w1 = lane * 3;
     int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    unsigned long long msk = __ballot(lane & 1), m0 = 0, m1 = 0;
+    asm volatile("v_cmp_lt_u32 vcc, 7, %0" : : "v"(lane) : "vcc");
     // LDS address: lane along consecutive dwords (conflict-free), wave-private 4 KB region
     const unsigned base = ((threadIdx.x >> 6) * 4096u) + lane * 4u;
     const unsigned base8 = ((threadIdx.x >> 6) * 4096u) + lane * 8u;
@@ -80,6 +85,36 @@ __global__ __launch_bounds__(256) void k_issue(int iters, unsigned long long *cy
         } else if (OP == CNDMASK) {
             R4(asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc"
                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4) : );)
+        } else if (OP == CNDMASK_IND) {
+            R4(asm volatile("v_cndmask_b32 %0, %4, %5, vcc\n v_cndmask_b32 %1, %5, %4, vcc\n v_cndmask_b32 %2, %4, %5, vcc\n v_cndmask_b32 %3, %5, %4, vcc"
+                            : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3) : "v"(a4), "v"(a5) : );)
+        } else if (OP == CNDMASK_SGPR) {
+            R4(asm volatile("v_cndmask_b32 %0, %4, %5, %6\n v_cndmask_b32 %1, %5, %4, %6\n v_cndmask_b32 %2, %4, %5, %6\n v_cndmask_b32 %3, %5, %4, %6"
+                            : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3) : "v"(a4), "v"(a5), "s"(msk) : );)
+        } else if (OP == MUL_HI_I32) {
+            R4(asm volatile("v_mul_hi_i32 %0, %0, %4\n v_mul_hi_i32 %1, %1, %4\n v_mul_hi_i32 %2, %2, %4\n v_mul_hi_i32 %3, %3, %4"
+                            : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(lane));)
+        } else if (OP == MUL_HI_U32) {
+            R4(asm volatile("v_mul_hi_u32 %0, %0, %4\n v_mul_hi_u32 %1, %1, %4\n v_mul_hi_u32 %2, %2, %4\n v_mul_hi_u32 %3, %3, %4"
+                            : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(lane));)
+        } else if (OP == MIN_U32) {
+            R4(asm volatile("v_min_u32 %0, %0, %4\n v_min_u32 %1, %1, %4\n v_min_u32 %2, %2, %4\n v_min_u32 %3, %3, %4"
+                            : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(lane));)
+        } else if (OP == CVT_RPI) {
+            R4(asm volatile("v_cvt_rpi_i32_f32 %0, %4\n v_cvt_rpi_i32_f32 %1, %4\n v_cvt_rpi_i32_f32 %2, %4\n v_cvt_rpi_i32_f32 %3, %4"
+                            : "=v"(u0), "=v"(u1), "=v"(u2), "=v"(u3) : "v"(a4));)
+        } else if (OP == PK_MUL) {
+            R4(asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4"
+                            : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(p0));)
+        } else if (OP == LSHL_ADD) {
+            R4(asm volatile("v_lshl_add_u32 %0, %0, 4, %4\n v_lshl_add_u32 %1, %1, 4, %4\n v_lshl_add_u32 %2, %2, 4, %4\n v_lshl_add_u32 %3, %3, 4, %4"
+                            : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(lane));)
+        } else if (OP == BFE_I32) {
+            R4(asm volatile("v_bfe_i32 %0, %0, 31, 1\n v_bfe_i32 %1, %1, 31, 1\n v_bfe_i32 %2, %2, 31, 1\n v_bfe_i32 %3, %3, 31, 1"
+                            : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : );)
+        } else if (OP == CMP_LT) {
+            R4(asm volatile("v_cmp_lt_u32 %0, %2, %3\n v_cmp_lt_u32 %1, %3, %2\n v_cmp_lt_u32 %0, %3, %2\n v_cmp_lt_u32 %1, %2, %3"
+                            : "=s"(m0), "=s"(m1) : "v"(u0), "v"(u1));)
         } else if (OP == PERMUTE) {
             R4(asm volatile("ds_permute_b32 %0, %4, %5\n ds_permute_b32 %1, %4, %5\n ds_permute_b32 %2, %4, %5\n ds_permute_b32 %3, %4, %5\n s_waitcnt lgkmcnt(0)"
                             : "=v"(u0), "=v"(u1), "=v"(u2), "=v"(u3) : "v"(base), "v"(lane));)
@@ -116,7 +151,7 @@ __global__ __launch_bounds__(256) void k_issue(int iters, unsigned long long *cy
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (lane == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
-    float r = a0 + a1 + a2 + a3 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + q0.x + q1.w + (float)(u0 + u1 + u2 + u3) + (float)(w0 + w1) + (float)(s0 + s1 + s2 + s3) + lds[lane];
+    float r = a0 + a1 + a2 + a3 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + q0.x + q1.w + (float)(u0 + u1 + u2 + u3) + (float)(w0 + w1) + (float)(s0 + s1 + s2 + s3) + (float)(m0 ^ m1) + lds[lane];
     if (r == 123.456f) sink[0] = r;
 }
 
@@ -168,6 +203,8 @@ int main()
     const double clk = p.clockRate / 1e6;
     run<FMA>(n_cu, clk); run<PK_FMA>(n_cu, clk); run<ADD_U32>(n_cu, clk); run<ADD64>(n_cu, clk); run<READLANE>(n_cu, clk); run<CVT>(n_cu, clk);
     run<MUL_LO>(n_cu, clk); run<MAD_U24>(n_cu, clk); run<DPP_MOV>(n_cu, clk); run<FLOOR>(n_cu, clk); run<FRACT>(n_cu, clk); run<CNDMASK>(n_cu, clk);
+    run<CNDMASK_IND>(n_cu, clk); run<CNDMASK_SGPR>(n_cu, clk); run<MUL_HI_I32>(n_cu, clk); run<MUL_HI_U32>(n_cu, clk); run<MIN_U32>(n_cu, clk);
+    run<CVT_RPI>(n_cu, clk); run<PK_MUL>(n_cu, clk); run<LSHL_ADD>(n_cu, clk); run<BFE_I32>(n_cu, clk); run<CMP_LT>(n_cu, clk);
     run<PERMUTE>(n_cu, clk);
     run<DS_READ_B32>(n_cu, clk); run<DS_READ2_B32>(n_cu, clk); run<DS_READ2ST64>(n_cu, clk); run<DS_READ_B64>(n_cu, clk); run<DS_READ_B128>(n_cu, clk);
     run<DS_ADD_U32>(n_cu, clk); run<DS_ADD_U64>(n_cu, clk); run<DS_ADD_F32>(n_cu, clk); run<DS_WRITE_B32>(n_cu, clk);
