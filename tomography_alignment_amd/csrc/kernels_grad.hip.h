@@ -2,6 +2,22 @@
 // Part of the single translation unit tomo_project.hip (included there, in this order: kernels_ray, kernels_tile,
 // kernels_grad); not compiled on its own.
 
+// floor(x) as an integer and x - floor(x), one instruction each (v_floor + v_sub + v_cvt before).  v_fract_f32 never returns
+// 1.0: for x a hair below an integer it gives 1 - 2^-24 where x - floorf(x) rounds to 1 -- a 6e-8 change of one weight.
+__device__ __forceinline__ int cvt_floor_i32(float x)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ float fract_f32(float x) { return __builtin_amdgcn_fractf(x); }
+__device__ __forceinline__ int med3_i32_s(int a_uniform, int b, int c)      // median of a wave-uniform value and two per-lane ones
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "s"(a_uniform), "v"(b), "v"(c));
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Shared tail of the gradient kernels: the per-ray 9x3 pose Jacobian applied ONCE to the accumulated S0 = sum_j grad_j and
 // S1 = sum_j sf_j grad_j (utilities/ray_voxel_utilities.py:38-49; same algebra as src/ray_wt_grad.f90:136-149), then either the
@@ -209,10 +225,8 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
             const bool two = jj + 1 < hi;
             const float xa = fmaf(ta, dxf, f0[0]), ya = fmaf(ta, dyf, f0[1]), za = fmaf(ta, dzf, f0[2]);
             const float xb = fmaf(tb, dxf, f0[0]), yb = fmaf(tb, dyf, f0[1]), zb = fmaf(tb, dzf, f0[2]);
-            const float fxa = floorf(xa), fya = floorf(ya), fza = floorf(za);
-            const float fxb = floorf(xb), fyb = floorf(yb), fzb = floorf(zb);
-            const uint32_t voa = off0 + (uint32_t)__mul24((int)fxa, (int)sx4) + (uint32_t)__mul24((int)fya, (int)sy4) + ((uint32_t)(int)fza << 2);
-            const uint32_t vob_ = off0 + (uint32_t)__mul24((int)fxb, (int)sx4) + (uint32_t)__mul24((int)fyb, (int)sy4) + ((uint32_t)(int)fzb << 2);
+            const uint32_t voa = off0 + (uint32_t)__mul24(cvt_floor_i32(xa), (int)sx4) + (uint32_t)__mul24(cvt_floor_i32(ya), (int)sy4) + ((uint32_t)cvt_floor_i32(za) << 2);
+            const uint32_t vob_ = off0 + (uint32_t)__mul24(cvt_floor_i32(xb), (int)sx4) + (uint32_t)__mul24(cvt_floor_i32(yb), (int)sy4) + ((uint32_t)cvt_floor_i32(zb) << 2);
             const uint32_t vob = two ? vob_ : voa;
             const f32x2 a00 = {*(const float *)(sb00 + voa), *(const float *)(sc00 + voa)};
             const f32x2 a01 = {*(const float *)(sb01 + voa), *(const float *)(sc01 + voa)};
@@ -223,7 +237,7 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
             const f32x2 b10 = {*(const float *)(sb10 + vob), *(const float *)(sc10 + vob)};
             const f32x2 b11 = {*(const float *)(sb11 + vob), *(const float *)(sc11 + vob)};
             {
-                const float wx = xa - fxa, wy = ya - fya, wz = za - fza;
+                const float wx = fract_f32(xa), wy = fract_f32(ya), wz = fract_f32(za);
                 const f32x2 dy0 = a01 - a00, dy1 = a11 - a10;          // d/dy on the x = 0 / x = 1 faces, at z and z + 1
                 const f32x2 c0 = a00 + wy * dy0, c1 = a10 + wy * dy1;  // y-lerped
                 const f32x2 dx = c1 - c0;                              // d/dx at z, z + 1
@@ -240,7 +254,7 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
             }
             {
                 const float keep = two ? 1.f : 0.f;
-                const float wx = xb - fxb, wy = yb - fyb, wz = zb - fzb;
+                const float wx = fract_f32(xb), wy = fract_f32(yb), wz = fract_f32(zb);
                 const f32x2 dy0 = b01 - b00, dy1 = b11 - b10;
                 const f32x2 c0 = b00 + wy * dy0, c1 = b10 + wy * dy1;
                 const f32x2 dx = c1 - c0;
@@ -346,24 +360,25 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
         // issue: addresses, the four gathers, and -- decided from the addresses alone -- the fallback gathers.
         // (Macros over plain scalars on purpose: a struct passed to helper lambdas was promoted to an LDS alloca, which put
         // a store of every loaded value -- hence a vmcnt(0) wait -- between the two samples' loads.)
-#define GS_DECL(S) float S##v000, S##v010, S##v100, S##v110, S##f001, S##f011, S##f101, S##f111, S##wx, S##wy, S##wz, S##t; /* f*: set and read only where fb */ \
-                   bool S##act, S##fb
+#define GS_DECL(S) float S##v000, S##v010, S##v100, S##v110, S##f001, S##f011, S##f101, S##f111, S##wx, S##wy, S##wz, S##t; /* f*: set, and selected, only where fb */ \
+                   unsigned long long S##actm, S##fbm /* lane masks: the sample is the lane's own; it loads its own upper corners */
 #define GS_ISSUE(S, JJ)                                                                                                            \
     {                                                                                                                              \
-        const int jc = min(max((JJ), lo_c), hi_c); /* own ray's nearest in-range sample */                                         \
-        S##act = has && jc == (JJ);                                                                                                \
+        const int jc = med3_i32_s((JJ), lo_c, hi_c); /* own ray's nearest in-range sample (lo_c <= hi_c) */                          \
+        S##actm = hm & __builtin_amdgcn_ballot_w64(jc == (JJ));                                                                    \
         S##t = (float)jc;                                                                                                          \
         const float x = fmaf(S##t, dxf, f0[0]), y = fmaf(S##t, dyf, f0[1]), z = fmaf(S##t, dzf, f0[2]);                            \
-        const float fx = floorf(x), fy = floorf(y), fz = floorf(z);                                                                \
-        S##wx = x - fx; S##wy = y - fy; S##wz = z - fz;                                                                            \
-        const uint32_t vo_own = off0 + (uint32_t)__mul24((int)fx, (int)sx4) + (uint32_t)__mul24((int)fy, (int)sy4) + ((uint32_t)(int)fz << 2); \
+        S##wx = fract_f32(x); S##wy = fract_f32(y); S##wz = fract_f32(z);                                                          \
+        const uint32_t vo_own = off0 + (uint32_t)__mul24(cvt_floor_i32(x), (int)sx4) + (uint32_t)__mul24(cvt_floor_i32(y), (int)sy4) + ((uint32_t)cvt_floor_i32(z) << 2); \
         const uint32_t vo = has ? vo_own : borrow;                                                                                 \
         S##v000 = *(const float *)(sb00 + vo); S##v010 = *(const float *)(sb01 + vo);                                              \
         S##v100 = *(const float *)(sb10 + vo); S##v110 = *(const float *)(sb11 + vo);                                              \
         const uint32_t nb = (uint32_t)dpp_shl1_i((int)vo); /* lane 63 receives 0: never vo + 4 */                                 \
         const uint32_t vo4 = vo + 4u;                                                                                              \
-        S##fb = S##act && nb != vo4;                                                                                               \
-        if (S##fb) { /* my upper-z cell is not the neighbour's lower-z cell */                                                     \
+        const bool fb = has && jc == (JJ) && nb != vo4;                                                                            \
+        S##fbm = S##actm & __builtin_amdgcn_ballot_w64(nb != vo4);                                                                 \
+        asm("" : "=v"(S##f001), "=v"(S##f011), "=v"(S##f101), "=v"(S##f111)); /* defined (no instruction); only fb lanes' values are selected */ \
+        if (fb) { /* my upper-z cell is not the neighbour's lower-z cell */                                                        \
             S##f001 = *(const float *)(sb00 + vo4); S##f011 = *(const float *)(sb01 + vo4);                                        \
             S##f101 = *(const float *)(sb10 + vo4); S##f111 = *(const float *)(sb11 + vo4);                                        \
         }                                                                                                                          \
@@ -373,23 +388,23 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
 #define GS_CONSUME(S)                                                                                                              \
     {                                                                                                                              \
         const float n001 = dpp_shl1_f(S##v000), n011 = dpp_shl1_f(S##v010), n101 = dpp_shl1_f(S##v100), n111 = dpp_shl1_f(S##v110);   \
-        const float v001 = S##fb ? S##f001 : n001, v011 = S##fb ? S##f011 : n011, v101 = S##fb ? S##f101 : n101, v111 = S##fb ? S##f111 : n111; \
-        /* scalar lerps on purpose: with the corners arriving one register at a time (loads, shifts, selects), packed ops     */ \
-        /* needed ~11 v_mov per sample just to pair their operands -- a fifth of this VALU-bound kernel's instructions      */ \
-        const float d00 = v001 - S##v000, d01 = v011 - S##v010, d10 = v101 - S##v100, d11 = v111 - S##v110; /* d/dz */             \
-        const float c00 = fmaf(S##wz, d00, S##v000), c01 = fmaf(S##wz, d01, S##v010);                                              \
-        const float c10 = fmaf(S##wz, d10, S##v100), c11 = fmaf(S##wz, d11, S##v110);            /* z-lerped corners */            \
-        const float dz0 = fmaf(S##wy, d01 - d00, d00), dz1 = fmaf(S##wy, d11 - d10, d10);                                          \
-        const float dy0 = c01 - c00, dy1 = c11 - c10;                                                                              \
-        const float e0 = fmaf(S##wy, dy0, c00), e1 = fmaf(S##wy, dy1, c10);                                                        \
-        const float keep = S##act ? 1.f : 0.f;                                                                                     \
-        const float gz = keep * fmaf(S##wx, dz1 - dz0, dz0);                                                                       \
-        const float gy = keep * fmaf(S##wx, dy1 - dy0, dy0);                                                                       \
-        const float gx0 = e1 - e0;                                                                                                 \
-        const float gx = keep * gx0;                                                                                               \
-        av = fmaf(keep, fmaf(S##wx, gx0, e0), av);                                                                                 \
-        const float sf = fmaf(S##t, sfs, sfb);                    /* (jb + jj) * step / |r0|, one rounding */                      \
-        a0x += gx; a0y += gy; a0z += gz;                                                                                           \
+        /* the lerps in z and y run on (x = 0, x = 1) register pairs -- the selected upper corners can be written to any       */ \
+        /* register, so pairing them is free -- as packed ops; the x stage is scalar                                            */ \
+        const f32x2 lo0 = {S##v000, S##v100}, lo1 = {S##v010, S##v110};                                                            \
+        const f32x2 up0 = {select_lanes2(n001, S##f001, S##fbm), select_lanes2(n101, S##f101, S##fbm)};                                  \
+        const f32x2 up1 = {select_lanes2(n011, S##f011, S##fbm), select_lanes2(n111, S##f111, S##fbm)};                                  \
+        const f32x2 d0 = up0 - lo0, d1 = up1 - lo1;                                  /* d/dz at y = 0, y = 1 */                    \
+        const f32x2 c0 = lo0 + S##wz * d0, c1 = lo1 + S##wz * d1;                    /* z-lerped corners */                        \
+        const f32x2 dz = d0 + S##wy * (d1 - d0);                                                                                   \
+        const f32x2 dy = c1 - c0;                                                                                                  \
+        const f32x2 e = c0 + S##wy * dy;                                                                                           \
+        const float keep = select_lanes(1.f, S##actm);                                                                             \
+        const float gz = fmaf(S##wx, dz.y - dz.x, dz.x);                                                                           \
+        const float gy = fmaf(S##wx, dy.y - dy.x, dy.x);                                                                           \
+        const float gx = e.y - e.x;                                                                                                \
+        av = fmaf(keep, fmaf(S##wx, gx, e.x), av);                                                                                 \
+        const float sf = keep * fmaf(S##t, sfs, sfb);             /* (jb + jj) * step / |r0|, one rounding; 0 where masked */      \
+        a0x = fmaf(keep, gx, a0x); a0y = fmaf(keep, gy, a0y); a0z = fmaf(keep, gz, a0z);                                           \
         a1x = fmaf(sf, gx, a1x); a1y = fmaf(sf, gy, a1y); a1z = fmaf(sf, gz, a1z);                                                 \
     }
         for (int jj = LO; jj < HI; jj += 2) {                                      // wave-uniform trip count; two samples in flight

@@ -19,12 +19,13 @@
 #define R16(x) R4(x) R4(x) R4(x) R4(x)
 
 enum Op { FMA, PK_FMA, ADD_U32, ADD64, READLANE, CVT, MUL_LO, MAD_U24, DPP_MOV, FLOOR, FRACT, CNDMASK, CNDMASK_IND, CNDMASK_SGPR, MUL_HI_I32, MUL_HI_U32, MIN_U32,
-          CVT_RPI, PK_MUL, LSHL_ADD, BFE_I32, CMP_LT, PERMUTE,
+          CVT_RPI, PK_MUL, LSHL_ADD, BFE_I32, CMP_LT, MIX_FMA_CND, CVT_FLR, MED3, CND_DPP, ADD64_ONE, PERMUTE,
           DS_READ_B32, DS_READ2_B32, DS_READ2ST64, DS_READ_B64, DS_READ_B128, DS_ADD_U32, DS_ADD_U64, DS_ADD_F32, DS_WRITE_B32, N_OPS };
 static const char *op_name[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_add_u32", "v_add_co+v_addc (64-bit add)", "v_readlane_b32", "v_cvt_f32_u32",
                                      "v_mul_lo_u32", "v_mad_u32_u24", "v_mov_b32 dpp wave_shl:1", "v_floor_f32", "v_fract_f32", "v_cndmask_b32",
                                      "v_cndmask_b32 (indep. dst, vcc set)", "v_cndmask_b32 (sgpr-pair mask)", "v_mul_hi_i32", "v_mul_hi_u32", "v_min_u32",
                                      "v_cvt_rpi_i32_f32", "v_pk_mul_f32", "v_lshl_add_u32", "v_bfe_i32", "v_cmp_lt_u32 (to sgpr pair)",
+                                     "3 v_fma_f32 + 1 v_cndmask vcc", "v_cvt_flr_i32_f32", "v_med3_i32", "v_cndmask_b32_dpp wave_shl:1 (vcc)", "v_lshl_add_u64 (v + s pair)",
                                      "ds_permute_b32", "ds_read_b32", "ds_read2_b32", "ds_read2st64_b32", "ds_read_b64", "ds_read_b128",
                                      "ds_add_u32", "ds_add_u64", "ds_add_f32", "ds_write_b32"};
 
@@ -115,6 +116,22 @@ __global__ __launch_bounds__(256) void k_issue(int iters, unsigned long long *cy
         } else if (OP == CMP_LT) {
             R4(asm volatile("v_cmp_lt_u32 %0, %2, %3\n v_cmp_lt_u32 %1, %3, %2\n v_cmp_lt_u32 %0, %3, %2\n v_cmp_lt_u32 %1, %2, %3"
                             : "=s"(m0), "=s"(m1) : "v"(u0), "v"(u1));)
+        } else if (OP == MIX_FMA_CND) {
+            R4(asm volatile("v_fma_f32 %0, %0, %4, %4\n v_fma_f32 %1, %1, %4, %4\n v_fma_f32 %2, %2, %4, %4\n v_cndmask_b32 %3, %3, %4, vcc"
+                            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4));)
+        } else if (OP == CVT_FLR) {
+            R4(asm volatile("v_cvt_flr_i32_f32 %0, %4\n v_cvt_flr_i32_f32 %1, %4\n v_cvt_flr_i32_f32 %2, %4\n v_cvt_flr_i32_f32 %3, %4"
+                            : "=v"(u0), "=v"(u1), "=v"(u2), "=v"(u3) : "v"(a4));)
+        } else if (OP == MED3) {
+            R4(asm volatile("v_med3_i32 %0, %0, %4, %5\n v_med3_i32 %1, %1, %4, %5\n v_med3_i32 %2, %2, %4, %5\n v_med3_i32 %3, %3, %4, %5"
+                            : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(lane), "v"(base));)
+        } else if (OP == CND_DPP) {
+            R4(asm volatile("v_cndmask_b32_dpp %0, %4, %5, vcc wave_shl:1 row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %1, %5, %4, vcc wave_shl:1 row_mask:0xf bank_mask:0xf\n"
+                            "v_cndmask_b32_dpp %2, %4, %5, vcc wave_shl:1 row_mask:0xf bank_mask:0xf\n v_cndmask_b32_dpp %3, %5, %4, vcc wave_shl:1 row_mask:0xf bank_mask:0xf"
+                            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4), "v"(a5) : );)
+        } else if (OP == ADD64_ONE) {
+            R4(asm volatile("v_lshl_add_u64 %0, %0, 0, %2\n v_lshl_add_u64 %1, %1, 0, %2\n v_lshl_add_u64 %0, %0, 0, %2\n v_lshl_add_u64 %1, %1, 0, %2"
+                            : "+v"(w0), "+v"(w1) : "s"(msk));)
         } else if (OP == PERMUTE) {
             R4(asm volatile("ds_permute_b32 %0, %4, %5\n ds_permute_b32 %1, %4, %5\n ds_permute_b32 %2, %4, %5\n ds_permute_b32 %3, %4, %5\n s_waitcnt lgkmcnt(0)"
                             : "=v"(u0), "=v"(u1), "=v"(u2), "=v"(u3) : "v"(base), "v"(lane));)
@@ -205,6 +222,7 @@ int main()
     run<MUL_LO>(n_cu, clk); run<MAD_U24>(n_cu, clk); run<DPP_MOV>(n_cu, clk); run<FLOOR>(n_cu, clk); run<FRACT>(n_cu, clk); run<CNDMASK>(n_cu, clk);
     run<CNDMASK_IND>(n_cu, clk); run<CNDMASK_SGPR>(n_cu, clk); run<MUL_HI_I32>(n_cu, clk); run<MUL_HI_U32>(n_cu, clk); run<MIN_U32>(n_cu, clk);
     run<CVT_RPI>(n_cu, clk); run<PK_MUL>(n_cu, clk); run<LSHL_ADD>(n_cu, clk); run<BFE_I32>(n_cu, clk); run<CMP_LT>(n_cu, clk);
+    run<MIX_FMA_CND>(n_cu, clk); run<CVT_FLR>(n_cu, clk); run<MED3>(n_cu, clk); run<CND_DPP>(n_cu, clk); run<ADD64_ONE>(n_cu, clk);
     run<PERMUTE>(n_cu, clk);
     run<DS_READ_B32>(n_cu, clk); run<DS_READ2_B32>(n_cu, clk); run<DS_READ2ST64>(n_cu, clk); run<DS_READ_B64>(n_cu, clk); run<DS_READ_B128>(n_cu, clk);
     run<DS_ADD_U32>(n_cu, clk); run<DS_ADD_U64>(n_cu, clk); run<DS_ADD_F32>(n_cu, clk); run<DS_WRITE_B32>(n_cu, clk);
