@@ -82,6 +82,12 @@ __device__ __forceinline__ float select_lanes2(float a, float b, unsigned long l
     return r;
 }
 
+// lane l <- lane l - 1 (lane 0 <- 0)
+__device__ __forceinline__ float dpp_shr1_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+
 // per-lane 64-bit position + wave-uniform 64-bit step in one VALU instruction, kept opaque so that the low word (the fraction)
 // and the high word (the cell) are used as they come (the compiler otherwise re-forms base + scalar offset and adds the low
 // words a second time)
@@ -771,9 +777,9 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
     const size_t n_det = (size_t)g.ndx * g.ndz;
     const uint32_t pitch4 = (uint32_t)g.ndz * 4u;                     // one projection's sinogram is < 4 GiB (host check)
     const float two_m32 = 2.3283064365386963e-10f;
-    float acc[64];
+    f32x2 acc2[32];                                                   // plane pairs (2k, 2k + 1)
 #pragma unroll
-    for (int p = 0; p < 64; ++p) acc[p] = 0.f;
+    for (int p = 0; p < 32; ++p) acc2[p] = f32x2{0.f, 0.f};
 
     // ---- 1. the weight table of this lane's column for projection IPX -> wtab[GRP % 3][IPX % GWAVES][lane].  The table does not
     //         depend on z: the four waves share it, wave w computes the projections 4 g + w (one barrier per four projections).
@@ -816,26 +822,29 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
     //          Straight-line on purpose (with a branch per row every row waited for its own round trip to memory).  The
     //          loads are consumed one projection later: they fly while the previous projection accumulates.
     float4 tn;
-    int ix_lo_n, nrows_n;
-    float y0v[GROWS], y1v[GROWS];
+    int ix_lo_n;
+    float y0v[GROWS], yedge;                                           // yedge: lane r holds row r one plane below the wave's first
 #define G_SETUP(IPX)                                                                                                       \
     {                                                                                                                      \
         tn = wtab[((IPX) / GWAVES) % 3][(IPX) % GWAVES][lane];                                                             \
         const int i0s = __builtin_bit_cast(int, tn.x);                                                                     \
         ix_lo_n = __builtin_amdgcn_readfirstlane(wave_min_i32(i0s));                                                       \
-        nrows_n = min(GROWS, __builtin_amdgcn_readfirstlane(wave_max_i32(i0s)) + 3 - ix_lo_n);                             \
         if (zlive) {                                                                                                       \
             const GfC &cn = cs[IPX];                                                                                       \
             const int iz0 = Zl - cn.zc;                                                                                    \
             const char *srow = (const char *)(proj + (size_t)cn.slot * n_det);                          /* wave-uniform */ \
-            /* one 32-bit byte offset per lane and plane shift, a wave-uniform 64-bit row base on the scalar unit: the loads */ \
-            /* take the saddr + voffset form (no 64-bit VALU add per load)                                                 */ \
-            const uint32_t o0 = (uint32_t)min(max(iz0, 0), g.ndz - 1) * 4u, o1 = (uint32_t)min(max(iz0 - 1, 0), g.ndz - 1) * 4u; \
-            _Pragma("unroll") for (int r = 0; r < GROWS; ++r) {                                                            \
-                const char *rb = srow + (uint32_t)min(max(ix_lo_n + r, 0), g.ndx - 1) * pitch4; /* wave-uniform, 32-bit scalar math */ \
-                y0v[r] = *(const float *)(rb + o0);                                                                        \
-                y1v[r] = *(const float *)(rb + o1);                                                                        \
-            }                                                                                                              \
+            /* addresses: the projection's base is a wave-uniform SGPR pair (saddr); the 32-bit voffset is the lane's plane     */ \
+            /* offset + the row's byte offset.  The 14 clamped row offsets are computed by 14 LANES at once and handed out    */ \
+            /* with v_readlane: per row one readlane and one add, no scalar clamp / multiply / 64-bit add (the kernel issued */ \
+            /* 335 SALU instructions per projection and wave against 290 VALU -- the scalar unit, one per CU, was the limit) */ \
+            const uint32_t o0 = (uint32_t)min(max(iz0, 0), g.ndz - 1) * 4u;                                                 \
+            const uint32_t rowoff = (uint32_t)min(max(ix_lo_n + min(lane, GROWS - 1), 0), g.ndx - 1) * pitch4;              \
+            _Pragma("unroll") for (int r = 0; r < GROWS; ++r)                                                              \
+                y0v[r] = *(const float *)(srow + (o0 + (uint32_t)__builtin_amdgcn_readlane((int)rowoff, r)));              \
+            /* the plane below (iz0 - 1) is the neighbouring lane's value (DPP shift when used); lane 0 has no neighbour: one  */ \
+            /* more load, lane r fetching row r at the wave's first plane - 1 -- 15 loads per projection instead of 28      */ \
+            const uint32_t oe = (uint32_t)min(max(z0 - cn.zc - 1, 0), g.ndz - 1) * 4u;                                      \
+            yedge = *(const float *)(srow + (rowoff + oe));                                                                \
         }                                                                                                                  \
     }
     const int n_grp = (n_proj + GWAVES - 1) / GWAVES;
@@ -850,17 +859,21 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
         for (int ip = grp * GWAVES; ip < min(n_proj, (grp + 1) * GWAVES); ++ip) {
             const GfC &c = cs[ip];
             const float4 t = tn;
-            const int i0 = __builtin_bit_cast(int, t.x), ix_lo = ix_lo_n, nrows = nrows_n;
+            const int i0 = __builtin_bit_cast(int, t.x), ix_lo = ix_lo_n;
             const float W0 = t.y, W1 = t.z, W2 = t.w;
             const bool hit = zlive && __any(W0 != 0.f || W1 != 0.f || W2 != 0.f);   // else this projection's rays miss the tile
             // ---- 2b. z-lerp the rows loaded one projection ago into the wave's LDS rows (lane = plane)
             if (hit) {
                 const int iz0 = Zl - c.zc, iz1 = iz0 - 1;
                 const bool ok0 = iz0 >= 0 && iz0 < g.ndz, ok1 = iz1 >= 0 && iz1 < g.ndz;
+                // (no per-row validity test: a row outside the detector was loaded from a clamped, valid address and every lane's
+                //  weight for it is 0 (G_TABLE); rows past the last one a lane needs are never read)
+                const unsigned long long m0 = __builtin_amdgcn_ballot_w64(ok0), m1 = __builtin_amdgcn_ballot_w64(ok1);
 #pragma unroll
                 for (int r = 0; r < GROWS; ++r) {
-                    const bool rowok = r < nrows && (unsigned)(ix_lo + r) < (unsigned)g.ndx;   // wave-uniform
-                    const float a0 = (rowok && ok0) ? y0v[r] : 0.f, a1 = (rowok && ok1) ? y1v[r] : 0.f;
+                    float y1 = dpp_shr1_f(y0v[r]);                                    // lane l <- lane l - 1: y(ix, iz0 - 1) for l >= 1
+                    asm("v_writelane_b32 %0, %1, 0" : "+v"(y1) : "s"(__builtin_amdgcn_readlane(__builtin_bit_cast(int, yedge), r)));   // lane 0 <- row r's edge value
+                    const float a0 = select_lanes(y0v[r], m0), a1 = select_lanes(y1, m1);
                     wrows[r * GPITCH + lane] = fmaf(c.tau, a1 - a0, a0);
                 }
             }
@@ -868,18 +881,21 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
             // ---- 3. accumulate, lane = column: its three rows start at slot0; plane p is an immediate offset.  The LDS rows were
             //         written by this same wave (LDS operations of a wave execute in order), no other wave touches them.
             if (hit) {
-                const int slot0 = min(max(i0 - ix_lo, 0), GROWS - 3);       // <= nrows - 3 by construction; clamped for safety
+                const int slot0 = min(max(i0 - ix_lo, 0), GROWS - 3);       // an 8 x 8 column tile touches <= 13 rows (7 (|cos| + |sin|) + 3); clamped for safety
                 // plane QUADS with ds_read_b128 (round 2): 256 B/clk where ds_read_b32 moves 128 B/clk -- the kernel was LDS-bound
                 // (SQ_LDS_IDX_ACTIVE = 0.79 of its cycles) on 3 x 64 dword reads per projection
                 const float4 *q = (const float4 *)__builtin_assume_aligned(wrows + slot0 * GPITCH, 16);
+                // two quads of reads in flight: quad p + 4 is issued before quad p is used (24 temporaries; with one quad in
+                // flight a wave had 6 packed FMAs to cover each LDS round trip)
+                float4 n0 = q[0], n1 = q[GPITCH / 4], n2 = q[2 * GPITCH / 4];
 #pragma unroll
                 for (int p = 0; p < 64; p += 4) {
-                    const float4 r0 = q[p / 4], r1 = q[(GPITCH + p) / 4], r2 = q[(2 * GPITCH + p) / 4];
-                    acc[p] = fmaf(W2, r2.x, fmaf(W1, r1.x, fmaf(W0, r0.x, acc[p])));
-                    acc[p + 1] = fmaf(W2, r2.y, fmaf(W1, r1.y, fmaf(W0, r0.y, acc[p + 1])));
-                    acc[p + 2] = fmaf(W2, r2.z, fmaf(W1, r1.z, fmaf(W0, r0.z, acc[p + 2])));
-                    acc[p + 3] = fmaf(W2, r2.w, fmaf(W1, r1.w, fmaf(W0, r0.w, acc[p + 3])));
-                    __builtin_amdgcn_sched_barrier(0);                       // one quad of reads in flight per wave: 12 temporaries, not 192 (4 waves per SIMD hide the latency)
+                    const float4 r0 = n0, r1 = n1, r2 = n2;
+                    if (p + 4 < 64) { n0 = q[(p + 4) / 4]; n1 = q[(GPITCH + p + 4) / 4]; n2 = q[(2 * GPITCH + p + 4) / 4]; }
+                    // plane pairs as packed FMAs (v_pk_fma_f32: two planes per instruction at 0.83 of the scalar rate)
+                    acc2[p / 2] = W2 * f32x2{r2.x, r2.y} + (W1 * f32x2{r1.x, r1.y} + (W0 * f32x2{r0.x, r0.y} + acc2[p / 2]));
+                    acc2[p / 2 + 1] = W2 * f32x2{r2.z, r2.w} + (W1 * f32x2{r1.z, r1.w} + (W0 * f32x2{r0.z, r0.w} + acc2[p / 2 + 1]));
+                    __builtin_amdgcn_sched_barrier(0);                       // keeps the reads from all being hoisted to the top (192 temporaries)
                 }
             }
         }
@@ -893,13 +909,13 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
 #pragma unroll
             for (int p = 0; p < 64; p += 4) {
                 float4 v = *(float4 *)(dst + p);
-                v.x += acc[p]; v.y += acc[p + 1]; v.z += acc[p + 2]; v.w += acc[p + 3];
+                v.x += acc2[p / 2].x; v.y += acc2[p / 2].y; v.z += acc2[p / 2 + 1].x; v.w += acc2[p / 2 + 1].y;
                 *(float4 *)(dst + p) = v;
             }
         } else {
 #pragma unroll
             for (int p = 0; p < 64; ++p)
-                if (z0 + p < g.nz) dst[p] += acc[p];
+                if (z0 + p < g.nz) dst[p] += (p & 1) ? acc2[p / 2].y : acc2[p / 2].x;
         }
     }
 }

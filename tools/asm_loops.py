@@ -6,7 +6,7 @@ from collections import Counter
 path, key = sys.argv[1], sys.argv[2]
 lines = open(path).read().splitlines()
 start = next(i for i, l in enumerate(lines) if re.match(r'^_Z\w*:', l) and key in l)
-end = next(i for i in range(start, len(lines)) if 's_endpgm' in lines[i])
+end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
 body = lines[start:end]
 labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r'^(\.LBB\d+_\d+):', l)] if m}
 loops = []
