@@ -865,17 +865,20 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
             // ---- 2b. z-lerp the rows loaded one projection ago into the wave's LDS rows (lane = plane)
             if (hit) {
                 const int iz0 = Zl - c.zc, iz1 = iz0 - 1;
-                const bool ok0 = iz0 >= 0 && iz0 < g.ndz, ok1 = iz1 >= 0 && iz1 < g.ndz;
                 // (no per-row validity test: a row outside the detector was loaded from a clamped, valid address and every lane's
                 //  weight for it is 0 (G_TABLE); rows past the last one a lane needs are never read)
-                const unsigned long long m0 = __builtin_amdgcn_ballot_w64(ok0), m1 = __builtin_amdgcn_ballot_w64(ok1);
-#pragma unroll
-                for (int r = 0; r < GROWS; ++r) {
-                    float y1 = dpp_shr1_f(y0v[r]);                                    // lane l <- lane l - 1: y(ix, iz0 - 1) for l >= 1
-                    asm("v_writelane_b32 %0, %1, 0" : "+v"(y1) : "s"(__builtin_amdgcn_readlane(__builtin_bit_cast(int, yedge), r)));   // lane 0 <- row r's edge value
-                    const float a0 = select_lanes(y0v[r], m0), a1 = select_lanes(y1, m1);
-                    wrows[r * GPITCH + lane] = fmaf(c.tau, a1 - a0, a0);
-                }
+                const unsigned long long m0 = __builtin_amdgcn_ballot_w64(iz0 >= 0) & __builtin_amdgcn_ballot_w64(iz0 < g.ndz);
+                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(iz1 >= 0) & __builtin_amdgcn_ballot_w64(iz1 < g.ndz);
+#define G_ZLERP(MASKED)                                                                                                           \
+    _Pragma("unroll") for (int r = 0; r < GROWS; ++r) {                                                                           \
+        float y1 = dpp_shr1_f(y0v[r]);                                            /* lane l <- lane l - 1: y(ix, iz0 - 1) for l >= 1 */ \
+        asm("v_writelane_b32 %0, %1, 0" : "+v"(y1) : "s"(__builtin_amdgcn_readlane(__builtin_bit_cast(int, yedge), r)));   /* lane 0 <- row r's edge value */ \
+        const float a0 = (MASKED) ? select_lanes(y0v[r], m0) : y0v[r], a1 = (MASKED) ? select_lanes(y1, m1) : y1;                \
+        wrows[r * GPITCH + lane] = fmaf(c.tau, a1 - a0, a0);                                                                      \
+    }
+                if ((m0 & m1) == ~0ull) { G_ZLERP(false) }                  // all 64 planes and their lower neighbours on the detector: the usual case
+                else { G_ZLERP(true) }
+#undef G_ZLERP
             }
             if (ip + 1 < n_proj) G_SETUP(ip + 1)                        // the next group's table is already published
             // ---- 3. accumulate, lane = column: its three rows start at slot0; plane p is an immediate offset.  The LDS rows were
