@@ -88,3 +88,72 @@ def test_tile_kernels_agree_with_ray_driven_kernels(seed):
         size = float(np.dot(np.abs(f_tile).astype(np.float64), np.abs(y).astype(np.float64)))     # the sums cancel: compare to the terms
         assert abs(lhs - rhs) <= 1e-5 * size + 1e-12
     print("worst rel-max: forward %.2e adjoint %.2e" % (worst_f, worst_a))
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_gradient_kernels_agree_on_random_geometry(seed):
+    """The gradient kernels over random shapes, detectors, steps and poses (tilts up to 6 degrees, rays that leave the volume, detector
+    rows shorter than a wave): the dword-gather (2), neighbour-shift (3) and per-pose dispatch (4) kernels form the same sums from the
+    same float32 positions (lerps in different orders) and agree per ray to a few 1e-6; the plain kernel (1) and the oracle (float64 positions) differ from them only by rounding,
+    which the fused reductions -- cost and the six gradient sums over all rays -- hold to 1e-5 of the terms they add."""
+    from oracle import oracle as orc
+    from tomography_alignment_amd import _lib
+    from tomography_alignment_amd.utilities.geometry import Geometry
+    from tomography_alignment_amd.utilities.projection_operators import ProjectionMatrix
+    rng = np.random.default_rng(7000 + seed)
+    worst_ray = worst_sum = 0.0
+    for k in range(6):
+        shape = tuple(int(v) for v in rng.integers(6, 72, 3))
+        ndet = (int(rng.integers(5, 80)), int(rng.integers(3, 140)))
+        step = float(rng.choice([1.0, 1.0, 0.5, 1.3]))
+        n = int(rng.integers(1, 4))
+        phi = rng.uniform(0, np.pi, n)
+        tilt = np.deg2rad(rng.choice([0.0, 0.5, 2.0, 6.0]))
+        alpha, beta = rng.uniform(-tilt, tilt, n), rng.uniform(-tilt, tilt, n)
+        xyz = rng.uniform(-4, 4, (n, 3))
+        cor = np.zeros((n, 3))
+        cor[:, 0] = rng.uniform(-1, 1, n)
+        geo = Geometry(n, np.array(shape), np.ones(3), np.array(ndet), np.ones(2), cor_shift=cor, step_size=step)
+        og = orc.Geo(n, np.array(shape), np.ones(3), np.array(ndet), np.ones(2), cor_shift=cor, step_size=step)
+        # a smooth volume: the gradient of a trilinear interpolant jumps at cell faces, so on white noise the float32 positions of the
+        # kernels (4e-6 voxel at coordinate 50) against the oracle's float64 ones already cost 1e-5 of the gradient sums
+        ii, jj, kk = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), np.arange(shape[2]), indexing="ij")
+        fr, ph = rng.uniform(0.05, 0.35, 3), rng.uniform(0, 6.28, 3)
+        x = (0.6 + 0.4 * np.cos(fr[0] * ii + ph[0]) * np.cos(fr[1] * jj + ph[1]) * np.cos(fr[2] * kk + ph[2])).astype(np.float32)
+        n_det = ndet[0] * ndet[1]
+        want_p = np.zeros((n, n_det))
+        want_g = np.zeros((n, 6, n_det))
+        for i in range(n):
+            want_p[i], want_g[i] = orc.projection_gradient(og, x, alpha[i], beta[i], phi[i], xyz[i], cor[i], precision=np.float64)
+        if np.max(np.abs(want_p)) == 0:
+            continue
+        b = (want_p + 0.05 * np.max(np.abs(want_p)) * rng.standard_normal(want_p.shape)).astype(np.float32)   # residual >> the float32 rounding of a projection
+        res = b.astype(np.float64) - want_p
+        want_c = 0.5 * np.sum(res * res, axis=1)
+        want_s = -np.einsum("ikr,ir->ik", want_g, res)
+        size_s = np.einsum("ikr,ir->ik", np.abs(want_g), np.abs(res))
+        # rows of one unit share a scale (the gradient along the beam, ty, is a difference of boundary terms: tiny on its own)
+        size_s = np.concatenate([np.repeat(size_s[:, :3].max(axis=1, keepdims=True), 3, axis=1), np.repeat(size_s[:, 3:].max(axis=1, keepdims=True), 3, axis=1)], axis=1) + 1e-30
+        poses = _lib.poses_array(phi, alpha, beta, xyz, cor)
+        P = ProjectionMatrix(geo)
+        be = P.backend
+        d_x, d_b = be.upload(x), be.upload(b)
+        rays = {}
+        for v in (1, 2, 3, 4):
+            be.ctx.set_option("grad_variant", v)
+            cost, g6 = be.cost_grad(poses, d_x, d_b)
+            assert np.allclose(cost, want_c, rtol=1e-5), ("cost", v, k, shape, ndet, step)
+            e = float(np.max(np.abs(g6 - want_s) / size_s))
+            worst_sum = max(worst_sum, e)
+            assert e < 1e-5, ("gradient sums", v, k, shape, ndet, step, np.rad2deg(tilt))
+            pr, gd = be.empty(n_det), be.empty(6 * n_det)
+            be.proj_grad(poses[:1], d_x, pr, gd)
+            rays[v] = (pr.download().copy(), gd.download().reshape(6, n_det).copy())
+        for v in (3, 4):
+            ep = rel_max(rays[v][0], rays[2][0])
+            gmax = [max(np.max(np.abs(rays[2][1][:3])), 1e-30)] * 3 + [max(np.max(np.abs(rays[2][1][3:])), 1e-30)] * 3      # per unit, as above
+            eg = max(float(np.max(np.abs(rays[v][1][r] - rays[2][1][r]))) / gmax[r] for r in range(6))
+            worst_ray = max(worst_ray, ep, eg)
+            assert ep < 2e-6 and eg < 5e-6, ("per ray", v, k, shape, ndet, step, np.rad2deg(tilt))    # float32 lerps in another order (2: y, x, z; 3: z, y, x)
+        assert rel_max(rays[1][0], want_p[0]) < 1e-5 and rel_max(rays[2][0], want_p[0]) < 1e-5
+    print("worst: per ray between kernels %.2e, fused sums vs oracle %.2e" % (worst_ray, worst_sum))

@@ -415,7 +415,7 @@ def test_gradient_kernel_variants_agree_on_odd_shapes(PM, orc, shape, ndet):
             for k in range(6):
                 assert rel_max(out[v][1][k], want_g[k]) < TOL, (v, k)
         assert rel_max(out[2][0], out[1][0]) < 5e-6 and rel_max(out[2][1], out[1][1]) < 5e-6    # float32 lerps in another order
-        assert rel_max(out[3][0], out[2][0]) < 1e-6 and rel_max(out[3][1], out[2][1]) < 1e-6    # same arithmetic, other data path
+        assert rel_max(out[3][0], out[2][0]) < 2e-6 and rel_max(out[3][1], out[2][1]) < 5e-6    # same positions; lerps z, y, x instead of y, x, z
 
 
 @pytest.mark.parametrize("case", ["lane63_only", "lane0_only", "short_row", "all_miss", "lane63_only_tilted", "one_row_tilted"])
