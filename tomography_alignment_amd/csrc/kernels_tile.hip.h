@@ -876,7 +876,11 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
         const float a0 = (MASKED) ? select_lanes(y0v[r], m0) : y0v[r], a1 = (MASKED) ? select_lanes(y1, m1) : y1;                \
         wrows[r * GPITCH + lane] = fmaf(c.tau, a1 - a0, a0);                                                                      \
     }
-                if ((m0 & m1) == ~0ull) { G_ZLERP(false) }                  // all 64 planes and their lower neighbours on the detector: the usual case
+                if (c.tau == 0.f) {                                         // samples sit exactly on detector rows (integer z shift: the nominal geometry
+#pragma unroll                                                              //  before alignment): Yz = y -- no neighbour plane, no lerp (fma(0, a1 - a0, a0) = a0)
+                    for (int r = 0; r < GROWS; ++r) wrows[r * GPITCH + lane] = select_lanes(y0v[r], m0);
+                }
+                else if ((m0 & m1) == ~0ull) { G_ZLERP(false) }             // all 64 planes and their lower neighbours on the detector: the usual case
                 else { G_ZLERP(true) }
 #undef G_ZLERP
             }
