@@ -287,7 +287,8 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
 // its own range still loads -- at its own ray's nearest in-range sample (always inside the padded volume), or, with no sample
 // in the block at all, at the first sample of the first lane that has one -- and its contribution is masked.  Since every
 // lane's values really are the volume at the address it advertises, "neighbour address == mine + 4" is all a lane must check.
-// The gathers are what bounds the gradient kernels under tilt (TA busy 100 %): time grows linearly with the tilt because
+// The gathers are what bounds the gradient kernels under tilt (TA busy 83-100 %; cutting the VALU work by 22 % in round 2 bought
+// 1-6 %): time grows linearly with the tilt because
 // a 16-lane group then straddles more volume rows; halving the gathers halves that term.
 // ------------------------------------------------------------------------------------------------
 // lane l <- lane l + 1; lane 63 <- 0 (bound_ctrl: no `old` register to initialise)

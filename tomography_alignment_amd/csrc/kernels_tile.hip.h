@@ -717,8 +717,9 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
 //      share it through a triple-buffered LDS table, one barrier per four projections;
 //   2. lane = PLANE: the z-lerped sinogram rows the tile can touch (<= 14) are loaded once (coalesced) into wave-private LDS
 //      rows (pitch 68 dwords: 16-byte aligned plane quads, lanes reading different rows hit different bank quads);
-//   3. lane = COLUMN again, 64 plane accumulators per lane (statically indexed registers): per plane 3 ds_read_b32 at
-//      row(lane) + immediate plane offset and 3 FMA with the lane's own W0..W2 -- no broadcasts, no address arithmetic.
+//   3. lane = COLUMN again, 64 plane accumulators per lane (statically indexed registers, as plane pairs): per four planes
+//      3 ds_read_b128 at row(lane) + immediate plane offset and 6 v_pk_fma_f32 with the lane's own W0..W2 -- no broadcasts, no
+//      address arithmetic.
 // Same sums as k_tile_flat<false> (which needs 4 ds_add_u32 per sample and lane), regrouped by voxel instead of by sample.
 // ------------------------------------------------------------------------------------------------
 #define GTX 8
@@ -817,10 +818,11 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
         }                                                                                                                  \
         wtab[((IPX) / GWAVES) % 3][(IPX) % GWAVES][lane] = t4;                                                             \
     }
-    // ---- 2a. fetch projection IPX's table entry and ISSUE the 32 loads of the sinogram rows the tile can touch: rows
-    //          ix_lo .. ix_lo+13 at this lane's PLANE (coalesced), from clamped -- always valid -- addresses, masked when used.
-    //          Straight-line on purpose (with a branch per row every row waited for its own round trip to memory).  The
-    //          loads are consumed one projection later: they fly while the previous projection accumulates.
+    // ---- 2a. fetch projection IPX's table entry and ISSUE the 15 loads of the sinogram rows the tile can touch: rows
+    //          ix_lo .. ix_lo+13 at this lane's PLANE (coalesced) plus one gather of their values one plane below the wave's
+    //          first, from clamped -- always valid -- addresses, masked when used.  Straight-line on purpose (with a branch per
+    //          row every row waited for its own round trip to memory).  The loads are consumed one projection later: they fly
+    //          while the previous projection accumulates.
     float4 tn;
     int ix_lo_n;
     float y0v[GROWS], yedge;                                           // yedge: lane r holds row r one plane below the wave's first
