@@ -404,6 +404,8 @@ def make_roofline(name, ms_per_step, launches_per_step, alg_bytes_per_pass, key)
             info["lds_frac_of_peak_bandwidth"] = round(sq["lds_bytes"] / t / 1e9 / LDS_PEAK_GBS, 4)
         if sq.get("SQ_INSTS_SALU"):
             info["salu_Ginstr_per_s"] = round(sq["SQ_INSTS_SALU"] / t / 1e9, 1)
+            # one scalar unit per CU: the gather back-projection was limited by it at 0.6 of one instruction per clock
+            info["salu_frac_of_one_per_clk_per_cu"] = round(sq["SQ_INSTS_SALU"] / t / 1e9 / (N_CU * CLK_GHZ), 4)
         r["instruction_rates"] = info
     return r
 
