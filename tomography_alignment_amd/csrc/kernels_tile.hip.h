@@ -538,7 +538,9 @@ template <int NZT>
 __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
                                                               const float *__restrict__ vol, TomoGeomC g)
 {
-    __shared__ float img[NZT][ALX * ALY * FLZ];
+    // the images of the NZT stacked tiles are INTERLEAVED per (x, y) cell: [x][y][tile][64 planes] -- every corner of every image of a
+    // sample then lies within ds_read2st64_b32's offset range (units of 256 B, < 256) of ONE address register
+    __shared__ float img[ALX * ALY * NZT * FLZ];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int z0 = -1 + (int)blockIdx.x * (NZT * FTZ), y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + (int)blockIdx.z * ATX;
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
             const int gx = x0 + lx, gy = y0 + ly, gz = z0 + k * FTZ + lz;
             float v = 0.f;
             if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz) v = vol[((size_t)gx * g.ny + gy) * g.nz + gz];
-            img[k][e] = v;
+            img[(t2 * NZT + k) * FLZ + lz] = v;
             any_nz |= (v != 0.f);
         }
         live[k] = __syncthreads_or(any_nz) != 0;                      // an all-zero tile contributes nothing to any ray
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
                     const int64_t px = (rbx + (int64_t)jc * k_fdx) + ldx, py = (rby + (int64_t)jc * k_fdy) + ldy;
                     const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32);
                     const bool own = (lx | ly) < (unsigned)ATX && jc + lane < jhi && lane < 60;
-                    const unsigned t_e = (__umul24(lx, ALY * FLZ) + __umul24(ly, FLZ)) * 4u;
+                    const unsigned t_e = (__umul24(lx, ALY * NZT * FLZ) + __umul24(ly, NZT * FLZ)) * 4u;
                     const float wx = (float)(unsigned)px * two_m32, wy = (float)(unsigned)py * two_m32;
                     const float t_w11 = wx * wy, t_w10 = wx - t_w11, t_w01 = wy - t_w11, t_w00 = 1.f - wx - t_w01;
                     // compact the owned samples to lanes 0 .. n_own-1 IN REGISTERS (ds_permute: lane i sends to its rank among the
@@ -636,28 +638,25 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
                     f32x2 Sa[NZT], Sb[NZT];
 #pragma unroll
                     for (int k = 0; k < NZT; ++k) { Sa[k] = (f32x2){0.f, 0.f}; Sb[k] = (f32x2){0.f, 0.f}; }
-                    // an entry's five readlanes serve every image; (q[0], q[FLZ]) arrive as a register pair from one
-                    // ds_read2st64 and the weights as SGPR pairs: two packed FMAs per sample and image.  Which images take part
-                    // is decided outside the loop (an all-zero or out-of-range image is skipped).
+                    // an entry's five readlanes serve every image.  One image in use: (y, y + 1) corners arrive as a register pair from
+                    // one ds_read2st64 and the weights as SGPR pairs, two packed FMAs per sample.  Both in use: see below.  Which images
+                    // take part is decided outside the loop (an all-zero or out-of-range image is skipped).
                     // SOFTWARE-PIPELINED (round 2): the reads of entry jj + 1 are issued before entry jj's values are used.  The
                     // one-entry-per-trip loop drained the LDS queue (s_waitcnt lgkmcnt(0)) before its last FMA, so every entry cost
                     // a wave a full LDS round trip, and with 4 waves per SIMD the kernel sat at 56 % LDS / ~30 % VALU utilisation:
                     // latency-bound.  Entries past n_own exist (ds_permute leaves 0 in lanes nobody wrote: address 0, weights 0), so
-                    // the look-ahead needs no guard.  The second image lies 73 984 B behind the first -- beyond the 16-bit DS offset
-                    // field: its base is formed once per entry and kept opaque, or the compiler folds the constant into four
-                    // separate ds_read_b32 addresses instead of two ds_read2st64_b32.
+                    // the look-ahead needs no guard.  (The images used to lie one behind the other, 73 984 B apart -- beyond the DS offset
+                    // fields, a second address register per entry; interleaved per cell, one register reaches all eight corners.)
                     {
                         int r_e = c_e, r_w00 = c_w00, r_w01 = c_w01, r_w10 = c_w10, r_w11 = c_w11;
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r_e), "+v"(r_w00), "+v"(r_w01), "+v"(r_w10), "+v"(r_w11));   // the permutes have landed: no waits on them inside the loop
 #define FZ_LOAD(T, J, K0, K1)                                                                                               \
                         {                                                                                                   \
                             const unsigned e_ = (unsigned)__builtin_amdgcn_readlane(r_e, (J)) + lane4;                      \
+                            const float *q_ = (const float *)((const char *)&img[0] + e_);                                  \
                             _Pragma("unroll") for (int k = (K0); k < (K1); ++k) {                                           \
-                                unsigned a_ = e_ + (unsigned)k * (unsigned)(ALX * ALY * FLZ * 4);                           \
-                                if (k) asm volatile("" : "+v"(a_));                                                         \
-                                const float *q_ = (const float *)((const char *)&img[0][0] + a_);                           \
-                                T##v0[k] = (f32x2){q_[0], q_[FLZ]};                                                         \
-                                T##v1[k] = (f32x2){q_[ALY * FLZ], q_[ALY * FLZ + FLZ]};                                     \
+                                T##v0[k] = (f32x2){q_[k * FLZ], q_[(NZT + k) * FLZ]};                                       \
+                                T##v1[k] = (f32x2){q_[(ALY * NZT + k) * FLZ], q_[(ALY * NZT + NZT + k) * FLZ]};             \
                             }                                                                                               \
                         }
 #define FZ_USE(T, J, K0, K1)                                                                                                \
@@ -677,7 +676,39 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
                                 FZ_USE(B_, jj + 1, K0, K1)                                                                  \
                             }                                                                                               \
                         }
-                        if (NZT == 2 && zuse[0] && zuse[NZT - 1]) { FZ_SAMPLE_LOOP(0, NZT) }
+                        if (NZT == 2 && zuse[0] && zuse[NZT - 1]) {
+                            // both images: a register pair = the SAME corner of image 0 and image 1 (adjacent 256-B units of the interleaved
+                            // layout, one ds_read2st64_b32), the weight a scalar for both halves: 4 reads + 4 packed FMAs per sample on one
+                            // address register
+                            f32x2 Pa = {0.f, 0.f}, Pb = {0.f, 0.f};
+                            f32x2 A_00, A_01, A_10, A_11, B_00, B_01, B_10, B_11;
+#define FB_LOAD(T, J)                                                                                                      \
+                            {                                                                                                   \
+                                const float *q_ = (const float *)((const char *)&img[0] + ((unsigned)__builtin_amdgcn_readlane(r_e, (J)) + lane4)); \
+                                T##00 = (f32x2){q_[0], q_[FLZ]}; T##01 = (f32x2){q_[2 * FLZ], q_[3 * FLZ]};                     \
+                                T##10 = (f32x2){q_[2 * ALY * FLZ], q_[(2 * ALY + 1) * FLZ]};                                    \
+                                T##11 = (f32x2){q_[(2 * ALY + 2) * FLZ], q_[(2 * ALY + 3) * FLZ]};                              \
+                            }
+#define FB_USE(T, J)                                                                                                       \
+                            {                                                                                                   \
+                                Pa += __int_as_float(__builtin_amdgcn_readlane(r_w00, (J))) * T##00;                            \
+                                Pb += __int_as_float(__builtin_amdgcn_readlane(r_w10, (J))) * T##10;                            \
+                                Pa += __int_as_float(__builtin_amdgcn_readlane(r_w01, (J))) * T##01;                            \
+                                Pb += __int_as_float(__builtin_amdgcn_readlane(r_w11, (J))) * T##11;                            \
+                            }
+                            static_assert(NZT <= 2, "the pair layout is written for two images");
+                            FB_LOAD(A_, 0)
+                            for (int jj = 0; jj < n_own; jj += 2) {
+                                FB_LOAD(B_, jj + 1)
+                                FB_USE(A_, jj)
+                                FB_LOAD(A_, jj + 2)
+                                FB_USE(B_, jj + 1)
+                            }
+#undef FB_LOAD
+#undef FB_USE
+                            const f32x2 Pt = Pa + Pb;
+                            Sa[0] = (f32x2){Pt.x, 0.f}; Sa[NZT - 1] = (f32x2){Sa[NZT - 1].x + (NZT == 2 ? Pt.y : 0.f), 0.f};
+                        }
                         else if (zuse[0]) { FZ_SAMPLE_LOOP(0, 1) }
                         else { FZ_SAMPLE_LOOP(NZT - 1, NZT) }
 #undef FZ_SAMPLE_LOOP
