@@ -74,6 +74,13 @@ __device__ __forceinline__ float select_lanes(float v, unsigned long long m)
     return r;
 }
 
+__device__ __forceinline__ unsigned select_lanes_u(unsigned v, unsigned long long m)
+{
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
+    return r;
+}
+
 // b where the lane's bit is set in m, else a
 __device__ __forceinline__ float select_lanes2(float a, float b, unsigned long long m)
 {
@@ -617,24 +624,29 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
 #pragma unroll
                 for (int k = 0; k < NZT; ++k) S[k] = 0.f;
                 for (int jc = jlo; jc < jhi; jc += 60) {
-                    // one lane per SAMPLE: cell, ownership in x,y and the four x,y weights of sample jc + lane
-                    const int64_t px = (rbx + (int64_t)jc * k_fdx) + ldx, py = (rby + (int64_t)jc * k_fdy) + ldy;
+                    // one lane per SAMPLE: cell, ownership in x,y and the four x,y weights of sample jc + lane.  The uniform part of
+                    // the position (row base + jc steps) is formed on the scalar unit and kept opaque -- the compiler otherwise
+                    // folds it into two per-lane 64-bit multiply-adds (v_mad_u64_u32)
+                    int64_t ux = rbx + (int64_t)jc * k_fdx, uy = rby + (int64_t)jc * k_fdy;
+                    asm volatile("" : "+s"(ux), "+s"(uy));
+                    const int64_t px = add64_vs(ldx, ux), py = add64_vs(ldy, uy);
                     const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32);
-                    const bool own = (lx | ly) < (unsigned)ATX && jc + lane < jhi && lane < 60;
+                    const unsigned long long own_m = __builtin_amdgcn_ballot_w64((lx | ly) < (unsigned)ATX) & __builtin_amdgcn_ballot_w64(jc + lane < min(jhi, jc + 60));
                     const unsigned t_e = (__umul24(lx, ALY * NZT * FLZ) + __umul24(ly, NZT * FLZ)) * 4u;
                     const float wx = (float)(unsigned)px * two_m32, wy = (float)(unsigned)py * two_m32;
                     const float t_w11 = wx * wy, t_w10 = wx - t_w11, t_w01 = wy - t_w11, t_w00 = 1.f - wx - t_w01;
-                    // compact the owned samples to lanes 0 .. n_own-1 IN REGISTERS (ds_permute: lane i sends to its rank among the
-                    // owned; the others send to lane 63, which is never read: n_own <= 60, and in practice a row owns <= 24
-                    // samples of a 16 x 16 tile; destination lanes nobody writes receive 0 = entries without effect).  The
-                    // sample loop then broadcasts an entry with v_readlane: LDS cycles go to the image reads only (a table entry
-                    // read from LDS cost 6.4 of the 16 LDS cycles per sample, tools/lds_read_bench.hip).
-                    const unsigned long long om = __ballot(own);
+                    // NO compaction: the owned samples of a row are CONTIGUOUS lanes (a line meets the tile's convex footprint in one
+                    // interval of j, and the cells come from exact fixed-point positions), so the sample loop simply broadcasts lanes
+                    // first .. first + n_own - 1 with v_readlane.  (Until round 2 the entries were compacted to lanes 0.. with five
+                    // ds_permute per row -- an LDS round trip in front of every row's loop; an ablation without the sample loop still took
+                    // 71 % of the kernel's time: the row set-up, not the samples, was the cost.)  Lanes that own nothing carry address 0 and
+                    // weights 0: the loop's look-ahead may read one or two of them.
+                    const unsigned long long om = own_m;
                     const int n_own = (int)__builtin_popcountll(om);
-                    const int dst4 = own ? 4 * (int)__builtin_amdgcn_mbcnt_hi((unsigned)(om >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)om, 0u)) : 4 * 63;
-                    const int c_e = __builtin_amdgcn_ds_permute(dst4, (int)t_e);
-                    const int c_w00 = __builtin_amdgcn_ds_permute(dst4, __float_as_int(t_w00)), c_w01 = __builtin_amdgcn_ds_permute(dst4, __float_as_int(t_w01));
-                    const int c_w10 = __builtin_amdgcn_ds_permute(dst4, __float_as_int(t_w10)), c_w11 = __builtin_amdgcn_ds_permute(dst4, __float_as_int(t_w11));
+                    const int first = om ? (int)__builtin_ctzll(om) : 0;
+                    const int c_e = (int)select_lanes_u(t_e, om);
+                    const int c_w00 = __float_as_int(select_lanes(t_w00, om)), c_w01 = __float_as_int(select_lanes(t_w01, om));
+                    const int c_w10 = __float_as_int(select_lanes(t_w10, om)), c_w11 = __float_as_int(select_lanes(t_w11, om));
                     f32x2 Sa[NZT], Sb[NZT];
 #pragma unroll
                     for (int k = 0; k < NZT; ++k) { Sa[k] = (f32x2){0.f, 0.f}; Sb[k] = (f32x2){0.f, 0.f}; }
@@ -649,10 +661,9 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
                     // fields, a second address register per entry; interleaved per cell, one register reaches all eight corners.)
                     {
                         int r_e = c_e, r_w00 = c_w00, r_w01 = c_w01, r_w10 = c_w10, r_w11 = c_w11;
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r_e), "+v"(r_w00), "+v"(r_w01), "+v"(r_w10), "+v"(r_w11));   // the permutes have landed: no waits on them inside the loop
 #define FZ_LOAD(T, J, K0, K1)                                                                                               \
                         {                                                                                                   \
-                            const unsigned e_ = (unsigned)__builtin_amdgcn_readlane(r_e, (J)) + lane4;                      \
+                            const unsigned e_ = (unsigned)__builtin_amdgcn_readlane(r_e, first + (J)) + lane4;                      \
                             const float *q_ = (const float *)((const char *)&img[0] + e_);                                  \
                             _Pragma("unroll") for (int k = (K0); k < (K1); ++k) {                                           \
                                 T##v0[k] = (f32x2){q_[k * FLZ], q_[(NZT + k) * FLZ]};                                       \
@@ -661,8 +672,8 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
                         }
 #define FZ_USE(T, J, K0, K1)                                                                                                \
                         {                                                                                                   \
-                            const f32x2 w0_ = {__int_as_float(__builtin_amdgcn_readlane(r_w00, (J))), __int_as_float(__builtin_amdgcn_readlane(r_w01, (J)))}; \
-                            const f32x2 w1_ = {__int_as_float(__builtin_amdgcn_readlane(r_w10, (J))), __int_as_float(__builtin_amdgcn_readlane(r_w11, (J)))}; \
+                            const f32x2 w0_ = {__int_as_float(__builtin_amdgcn_readlane(r_w00, first + (J))), __int_as_float(__builtin_amdgcn_readlane(r_w01, first + (J)))}; \
+                            const f32x2 w1_ = {__int_as_float(__builtin_amdgcn_readlane(r_w10, first + (J))), __int_as_float(__builtin_amdgcn_readlane(r_w11, first + (J)))}; \
                             _Pragma("unroll") for (int k = (K0); k < (K1); ++k) { Sa[k] += w0_ * T##v0[k]; Sb[k] += w1_ * T##v1[k]; } \
                         }
 #define FZ_SAMPLE_LOOP(K0, K1)                                                                                              \
@@ -684,17 +695,17 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
                             f32x2 A_00, A_01, A_10, A_11, B_00, B_01, B_10, B_11;
 #define FB_LOAD(T, J)                                                                                                      \
                             {                                                                                                   \
-                                const float *q_ = (const float *)((const char *)&img[0] + ((unsigned)__builtin_amdgcn_readlane(r_e, (J)) + lane4)); \
+                                const float *q_ = (const float *)((const char *)&img[0] + ((unsigned)__builtin_amdgcn_readlane(r_e, first + (J)) + lane4)); \
                                 T##00 = (f32x2){q_[0], q_[FLZ]}; T##01 = (f32x2){q_[2 * FLZ], q_[3 * FLZ]};                     \
                                 T##10 = (f32x2){q_[2 * ALY * FLZ], q_[(2 * ALY + 1) * FLZ]};                                    \
                                 T##11 = (f32x2){q_[(2 * ALY + 2) * FLZ], q_[(2 * ALY + 3) * FLZ]};                              \
                             }
 #define FB_USE(T, J)                                                                                                       \
                             {                                                                                                   \
-                                Pa += __int_as_float(__builtin_amdgcn_readlane(r_w00, (J))) * T##00;                            \
-                                Pb += __int_as_float(__builtin_amdgcn_readlane(r_w10, (J))) * T##10;                            \
-                                Pa += __int_as_float(__builtin_amdgcn_readlane(r_w01, (J))) * T##01;                            \
-                                Pb += __int_as_float(__builtin_amdgcn_readlane(r_w11, (J))) * T##11;                            \
+                                Pa += __int_as_float(__builtin_amdgcn_readlane(r_w00, first + (J))) * T##00;                            \
+                                Pb += __int_as_float(__builtin_amdgcn_readlane(r_w10, first + (J))) * T##10;                            \
+                                Pa += __int_as_float(__builtin_amdgcn_readlane(r_w01, first + (J))) * T##01;                            \
+                                Pb += __int_as_float(__builtin_amdgcn_readlane(r_w11, first + (J))) * T##11;                            \
                             }
                             static_assert(NZT <= 2, "the pair layout is written for two images");
                             FB_LOAD(A_, 0)
