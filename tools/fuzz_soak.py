@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run tests/test_gpu_fuzz.py's cross-check over many seeds (development aid): python tools/fuzz_soak.py [first] [last]"""
+"""Run tests/test_gpu_fuzz.py's two cross-checks (tile kernels, gradient kernels) over many seeds (development aid): python tools/fuzz_soak.py [first] [last]"""
 import os
 import sys
 
@@ -11,4 +11,5 @@ import test_gpu_fuzz as f      # noqa: E402
 a, b = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4, 40)
 for seed in range(a, b):
     f.test_tile_kernels_agree_with_ray_driven_kernels(seed)
+    f.test_gradient_kernels_agree_on_random_geometry(seed)
 print("seeds %d..%d ok" % (a, b - 1))
