@@ -338,3 +338,14 @@ def test_bench_launcher_and_roofline_logic_without_a_gpu(tmp_path, monkeypatch):
     assert r["instruction_rates"]["lds_GBps"] > 0
     r2 = bench.make_roofline("k_fwd_tile_flat", 500.0, 1.0, 4.4e12, "other-workload")
     assert r2["bound"] == "hbm" and r2["counters"] is None and "no committed PMC counters" in r2["note"]
+
+
+def test_samples_per_ray_match_numpy_rounding():
+    """n = int(|r0| / step) (utilities/ray_voxel_utilities.py:88) hangs on the rounding of a length that is an integer in exact
+    arithmetic; the library's host code (csrc/tomo_raycore.h, built here as a plain C++ program) rounds its 3-term inner products the
+    way numpy's np.dot does and must give numpy's n -- and |r0| bit for bit -- for every pose (it differed for 8 % of them before)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("n_check", os.path.join(ROOT, "tools", "n_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(600) == 0
