@@ -107,7 +107,7 @@ TOMO_API int tomo_set_option(tomo_ctx *ctx, const char *key, int value);
  * tomo_check_geometry is the validation tomo_set_geometry applies, callable without a context or a GPU: TOMO_ERR_ARG for
  * non-positive shapes / step or det_y <= src_y, TOMO_ERR_UNSUPPORTED for a zero-padded volume of 2^31 voxels or more;
  * *flags (nullable) receives TOMO_GEOM_* bits: WIDE_ROWS = one padded x-row ((ny+4)*(nz+4) floats) spans 2^23 bytes or
- * more (a slab such as 16 x 2048 x 2048), or the detector-z pitch exceeds one voxel -- geometries for which the ray-driven
+ * more (a slab such as 16 x 2048 x 2048), or the detector-z pitch or the sample step exceeds one voxel -- geometries for which the ray-driven
  * kernels with 24-bit offset multiplies and fixed lane biases (fwd_variant 2, grad_variant 2-4) are replaced by their plain
  * 64-bit-indexing twins (variant 1): same results, slower. */
 #define TOMO_GEOM_WIDE_ROWS 1

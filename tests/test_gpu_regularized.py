@@ -19,6 +19,9 @@ def test_soft_threshold_vs_reference_golden():
     d = regularized.soft_thresholding(ctx.to_device(g["st_x"].reshape(64, 64)), float(g["st_lambda"]))
     assert isinstance(d, _lib.DeviceArray) and np.array_equal(d.download().ravel(), g["st_out"])
     assert np.array_equal(regularized.soft_thresholding(np.zeros(0, np.float32), 1.0), np.zeros(0, np.float32))
+    # float64 in -> float32 out: the device computes in float32 and says so, never float32 values labelled float64
+    o64 = regularized.soft_thresholding(g["st_x"].astype(np.float64), float(g["st_lambda"]))
+    assert o64.dtype == np.float32 and np.array_equal(o64, g["st_out"])
 
 
 def test_tv_denoise_fista_vs_reference_golden(capsys):
@@ -55,3 +58,9 @@ def test_tv_denoise_fista_vs_reference_golden(capsys):
     assert tv_denoise.tv_norm_3d(got) < 0.6 * tv_denoise.tv_norm_3d(d)                  # it does denoise
     with pytest.raises(_lib.TomoError):
         tv_denoise.denoise_fista(np.zeros((4, 1, 4), np.float32), weight=1.0)            # the reference's div needs >= 2 per axis
+    # float64 in -> float32 out; a second call of another size reuses / regrows the context's workspace; the module
+    # context can be closed explicitly and is re-created on demand
+    o64 = tv_denoise.denoise_fista(im.astype(np.float64), **cases["a"])
+    assert o64.dtype == np.float32 and rel_max(o64, g["tv_a"]) < 1e-5
+    tv_denoise.close_context()
+    assert tv_denoise._ctx is None and rel_max(tv_denoise.denoise_fista(im, **cases["a"]), g["tv_a"]) < 1e-5

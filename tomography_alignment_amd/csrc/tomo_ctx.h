@@ -31,7 +31,7 @@ struct tomo_ctx {
     size_t volpad_elems = 0;
     size_t volpad_rows = 0;             // nx * ny the row scratch behind the padded copy was sized for
     bool halo_dirty = true;
-    bool wide_rows = false;             // TOMO_GEOM_WIDE_ROWS: a padded x-row pitch >= 2^24 bytes -- the 24-bit-multiply kernels are not used
+    bool wide_rows = false;             // TOMO_GEOM_WIDE_ROWS: padded x-row pitch >= 2^23 bytes, detector-z pitch or sample step > 1 voxel -- the 24-bit-multiply / fixed-bias kernels are not used
     const void *staged_src = nullptr;   // device pointer whose contents the padded copy currently holds
     int reuse_staged = 0;               // caller vouches: contents of staged_src unchanged since it was staged
     // per-projection constants (pinned host staging + device)
@@ -52,6 +52,9 @@ struct tomo_ctx {
     double *d_red = nullptr;
     double *h_red = nullptr;
     size_t red_cap = 0;     // doubles
+    // general float workspace (grow-only): the TV-FISTA proximal step keeps its 7 fields here across calls
+    float *d_ws = nullptr;
+    size_t ws_elems = 0;
     // options
     int fwd_variant = 3;      // 1 ray-driven plain, 2 ray-driven SGPR-base, 3 LDS tile (default)
     int adj_variant = 2;      // 1 global float atomics, 2 LDS tile fixed-point (default)
@@ -77,6 +80,7 @@ struct tomo_ctx {
 int tomo_fail(tomo_ctx *ctx, int code, const std::string &msg);
 int tomo_ensure_stage(tomo_ctx *ctx, size_t bytes);
 int tomo_ensure_red(tomo_ctx *ctx, size_t n_doubles);
+int tomo_ensure_ws(tomo_ctx *ctx, size_t n_floats);
 void tomo_prof_begin(tomo_ctx *ctx, const char *name);
 void tomo_prof_end(tomo_ctx *ctx);
 void tomo_prof_begin_on(tomo_ctx *ctx, const char *name, hipStream_t stream);

@@ -62,6 +62,7 @@ extern "C" int tomo_ctx_destroy(tomo_ctx *c)
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_red) (void)hipFree(c->d_red);
     if (c->h_red) (void)hipHostFree(c->h_red);
+    if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -177,6 +178,18 @@ int tomo_ensure_red(tomo_ctx *ctx, size_t n)
     return TOMO_OK;
 }
 
+int tomo_ensure_ws(tomo_ctx *ctx, size_t n)
+{
+    if (n <= ctx->ws_elems) return TOMO_OK;
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    ctx->d_ws = nullptr;
+    ctx->ws_elems = 0;
+    TOMO_HIP(ctx, hipMalloc((void **)&ctx->d_ws, n * sizeof(float)));
+    ctx->ws_elems = n;
+    return TOMO_OK;
+}
+
 // Pure host check shared by tomo_set_geometry and callers without a context (tests run it on CPU).
 extern "C" int tomo_check_geometry(const tomo_geom *g, int *flags)
 {
@@ -187,8 +200,12 @@ extern "C" int tomo_check_geometry(const tomo_geom *g, int *flags)
     const size_t nxp = (size_t)g->nx + 2 * TOMO_HALO, nyp = (size_t)g->ny + 2 * TOMO_HALO, nzp = (size_t)g->nz + 2 * TOMO_HALO;
     if (nxp * nyp * nzp >= ((size_t)1 << 31)) return tomo_fail(nullptr, TOMO_ERR_UNSUPPORTED, "set_geometry: padded volume exceeds 2^31 voxels");
     // the SGPR-base kernels (k_fwd_v2, k_proj_grad_v2/_v3) form lane offsets with SIGNED 24-bit multiplies: cell * (row pitch in bytes)
-    // ... and bias a wave's lane offsets by 66 cells per axis, which covers 64 rays only while the detector-z pitch <= 1 voxel
-    if (nyp * nzp * 4 >= ((size_t)1 << 23) || nzp * 4 >= ((size_t)1 << 23) || !(fabs(g->det_dz) <= 1.0 + 1e-9)) { if (flags) *flags |= TOMO_GEOM_WIDE_ROWS; }
+    // ... bias a wave's lane offsets by TOMO_LBIAS = 66 cells per axis, which covers 64 rays only while the detector-z pitch <= 1 voxel
+    // ... and address a block's cells relative to its mid-block anchor with a bias of TOMO_ABIAS = 18 cells: in-block cells lie
+    // within +-(15.5 |d_a| + 1) of the anchor, i.e. within +-17 only while the sample step is <= 1 voxel (with step 1.3
+    // the range is +-21 and only the slack of the lane bias kept the unsigned offsets from wrapping; beyond ~5 voxels they
+    // would).  Such geometries take the plain 64-bit kernels (variant 1), which have no such assumption.
+    if (nyp * nzp * 4 >= ((size_t)1 << 23) || nzp * 4 >= ((size_t)1 << 23) || !(fabs(g->det_dz) <= 1.0 + 1e-9) || !(g->step <= 1.0 + 1e-9)) { if (flags) *flags |= TOMO_GEOM_WIDE_ROWS; }
     return TOMO_OK;
 }
 

@@ -175,7 +175,8 @@ TOMO_HD void tomo_ray_range(const double b[3], const double d[3], int n, int nx,
 }
 
 // Block anchor: the integer floor of the block's MIDDLE position, so the float32 in-block coordinates x = f0 + jj*d stay within
-// +-(TOMO_JB/2 * |d| + 1) <= +-17: float32 rounding of a sample position <= ~1e-6 voxel (f0 and the fma each round at
+// +-(TOMO_JB/2 * |d| + 1) <= +-17 FOR A SAMPLE STEP <= 1 VOXEL (tomo_check_geometry routes step > 1 to the plain 64-bit kernels,
+// which call this with the same arithmetic but do not rely on the range; their accuracy degrades as step * 1e-6): float32 rounding of a sample position <= ~1e-6 voxel (f0 and the fma each round at
 // ulp(16) = 1.9e-6 at the block ends, 2.4e-7 in the middle) -- half of what an anchor below the block's lowest corner gave
 // (coordinates up to 35), which at 512^3 left the pose gradient only just inside 1e-5 of the float64 reference on a
 // piecewise-constant phantom (tests/test_gpu_configs.py).  Cells relative to the anchor lie in [-TOMO_ABIAS + 1, TOMO_ABIAS - 1]:

@@ -164,46 +164,40 @@ extern "C" int tomo_tv_denoise_fista(tomo_ctx *ctx, const float *d_im, float *d_
     rc = tomo_ensure_red(ctx, 8);
     if (rc) return rc;
     const size_t n = (size_t)nx * ny * nz;
-    float *ws = nullptr;
     TOMO_HIP(ctx, hipSetDevice(ctx->device));
-    TOMO_HIP(ctx, hipMalloc((void **)&ws, 7 * n * sizeof(float)));      // grad_aux[3], grad_im[3], err
+    // grad_aux[3], grad_im[3], err: kept in the context across calls (grow-only, like d_stage / d_red) -- a proximal step per
+    // outer iteration of a regularised solver used to pay a 7 n hipMalloc + hipFree (28 GB at 1024^3, each an implicit device sync)
+    rc = tomo_ensure_ws(ctx, 7 * n);
+    if (rc) return rc;
+    float *ws = ctx->d_ws;
     float *ax = ws, *ay = ws + n, *az = ws + 2 * n, *px = ws + 3 * n, *py = ws + 4 * n, *pz = ws + 5 * n, *err = ws + 6 * n;
-    int result = TOMO_OK;
     double dgap = 0.0;
     int i = 0;
-    do {
-        if (hipMemsetAsync(ws, 0, 6 * n * sizeof(float), ctx->stream) != hipSuccess ||                               // :144-145
-            hipMemcpyAsync(d_out, d_im, n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {  // new = im.copy()  :148
-            result = tomo_fail(ctx, TOMO_ERR_HIP, "tomo_tv_denoise_fista: initialisation failed");
-            break;
+    if (h_iters) *h_iters = 0;
+    if (h_dual_gap) *h_dual_gap = 0.0;
+    TOMO_HIP(ctx, hipMemsetAsync(ws, 0, 6 * n * sizeof(float), ctx->stream));                                        // :144-145
+    TOMO_HIP(ctx, hipMemcpyAsync(d_out, d_im, n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));           // new = im.copy()  :148
+    const float w = (float)weight, c = (float)(1.0 / (12.0 * weight));                                               // factor 12 for 3-D  :139-142,153
+    double t = 1.0;
+    while (i < niter) {                                                                                              // :149
+        TOMO_LAUNCH(ctx, "k_tv_error", k_tv_error, grid, dim3(256), 0, (const float *)ax, (const float *)ay, (const float *)az, d_im, err, d, w);
+        const double t_new = 0.5 * (1.0 + sqrt(1.0 + 4.0 * t * t)), t_factor = (t - 1.0) / t_new;                   // :156-157
+        TOMO_LAUNCH(ctx, "k_tv_update", k_tv_update, grid, dim3(256), 0, ax, ay, az, px, py, pz, (const float *)err, d, c, (float)(1.0 + t_factor), (float)t_factor);
+        t = t_new;
+        if (i % check_gap_frequency == 0) {                                                                          // :161-166
+            TOMO_HIP(ctx, hipMemsetAsync(ctx->d_red, 0, 4 * sizeof(double), ctx->stream));
+            TOMO_LAUNCH(ctx, "k_tv_new", k_tv_new, grid, dim3(256), 0, (const float *)px, (const float *)py, (const float *)pz, d_im, d_out, d, w, ctx->d_red);
+            TOMO_LAUNCH(ctx, "k_tv_norm", k_tv_norm<1>, grid, dim3(256), 0, (const float *)d_out, d, ctx->d_red + 3);
+            TOMO_HIP(ctx, hipMemcpyAsync(ctx->h_red, ctx->d_red, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            const double s_gap = ctx->h_red[0], s_new = ctx->h_red[1], im_norm = ctx->h_red[2], tv_new = 2.0 * weight * ctx->h_red[3];
+            dgap = im_norm > 0.0 ? 0.5 / im_norm * (s_gap + tv_new - im_norm + s_new) : 0.0;                        // :93-95
+            if (dgap < eps) break;                                                                                   // :165-166 (i is not advanced)
         }
-        const float w = (float)weight, c = (float)(1.0 / (12.0 * weight));                                           // factor 12 for 3-D  :139-142,153
-        double t = 1.0;
-        while (i < niter) {                                                                                          // :149
-            hipLaunchKernelGGL(k_tv_error, grid, dim3(256), 0, ctx->stream, (const float *)ax, (const float *)ay, (const float *)az, d_im, err, d, w);
-            const double t_new = 0.5 * (1.0 + sqrt(1.0 + 4.0 * t * t)), t_factor = (t - 1.0) / t_new;               // :156-157
-            hipLaunchKernelGGL(k_tv_update, grid, dim3(256), 0, ctx->stream, ax, ay, az, px, py, pz, (const float *)err, d, c, (float)(1.0 + t_factor), (float)t_factor);
-            t = t_new;
-            if (i % check_gap_frequency == 0) {                                                                      // :161-166
-                (void)hipMemsetAsync(ctx->d_red, 0, 4 * sizeof(double), ctx->stream);
-                hipLaunchKernelGGL(k_tv_new, grid, dim3(256), 0, ctx->stream, (const float *)px, (const float *)py, (const float *)pz, d_im, d_out, d, w, ctx->d_red);
-                hipLaunchKernelGGL(k_tv_norm<1>, grid, dim3(256), 0, ctx->stream, (const float *)d_out, d, ctx->d_red + 3);
-                if (hipMemcpyAsync(ctx->h_red, ctx->d_red, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                    hipStreamSynchronize(ctx->stream) != hipSuccess) {
-                    result = tomo_fail(ctx, TOMO_ERR_HIP, "tomo_tv_denoise_fista: gap check failed");
-                    break;
-                }
-                const double s_gap = ctx->h_red[0], s_new = ctx->h_red[1], im_norm = ctx->h_red[2], tv_new = 2.0 * weight * ctx->h_red[3];
-                dgap = im_norm > 0.0 ? 0.5 / im_norm * (s_gap + tv_new - im_norm + s_new) : 0.0;                    // :93-95
-                if (dgap < eps) break;                                                                               // :165-166 (i is not advanced)
-            }
-            ++i;
-        }
-        if (result == TOMO_OK && hipGetLastError() != hipSuccess) result = tomo_fail(ctx, TOMO_ERR_HIP, "tomo_tv_denoise_fista: kernel launch failed");
-    } while (0);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(ws);
+        ++i;
+    }
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (h_iters) *h_iters = i;
     if (h_dual_gap) *h_dual_gap = dgap;
-    return result;
+    return TOMO_OK;
 }

@@ -15,8 +15,9 @@ except ImportError:      # imported as top-level `recon`
 
 
 def soft_thresholding(x, _lambda, ctx=None):
-    """x - l where x > l, x + l where x < -l, else 0.  numpy in -> numpy out (same dtype and shape); DeviceArray in ->
-    a new DeviceArray."""
+    """x - l where x > l, x + l where x < -l, else 0.  numpy in -> numpy float32 out (same shape); DeviceArray in -> a new
+    DeviceArray.  The device computes in float32: a float64 input comes back as FLOAT32, not as float32 values labelled
+    float64 (the reference computes in the input's dtype)."""
     if isinstance(x, _lib.DeviceArray):
         c = x.ctx
         out = c.empty(x.shape)
@@ -26,4 +27,4 @@ def soft_thresholding(x, _lambda, ctx=None):
     c = _tv._context(ctx)
     d = c.to_device(a.ravel())
     c.check(c.lib.tomo_vec_soft_threshold(c.handle, d.ptr, d.ptr, d.size, float(_lambda)))
-    return d.download().reshape(a.shape).astype(a.dtype if a.dtype.kind == 'f' else np.float32, copy=False)
+    return d.download().reshape(a.shape)

@@ -182,12 +182,15 @@ class ProjectionMatrix(object):
         self.xyz_shift = None
         self.voxel_mask = None
         self._backend = backend
-        self._vol_dev = None          # device buffer of the volume last passed to projection_gradient / cost_and_gradient
-        self._vol_own = False         # ... allocated here (host uploads) as opposed to handed in by the caller
+        self._vol_dev = None          # device buffer of the UNPINNED volume last passed to projection_gradient / cost_and_gradient
+        self._vol_own = None          # ... the scratch buffer host uploads of unpinned volumes go to
         self._vol_gen = 0             # bumped by every (re)load; memo keys carry it
         self._pinned = None           # the object the caller pinned (identity), see pin_volume()
+        self._pin_dev = None          # device buffer holding the pinned volume; never shared with unpinned volumes
+        self._pin_own = None          # ... when it was uploaded from a host array
         self._pin_stale = False
-        self._vol_staged = False      # True once the library has staged the PINNED volume and nothing has changed it since
+        self._last_was_pinned = False  # the volume set_volume() returned last was the pinned one
+        self._vol_staged = False      # True while the library's zero-padded copy holds the PINNED volume, unchanged
         self._pg_bufs = None
 
     @property
@@ -237,13 +240,13 @@ class ProjectionMatrix(object):
         """Keep `rec` (host array or DeviceArray) resident in HBM: subsequent calls that pass this very object skip the
         upload and the zero-padded staging.  The caller vouches that the contents do not change until unpin_volume() /
         invalidate_volume()."""
-        self._pinned = None
-        vol = self._load_volume(rec)
         self._pinned = rec
-        return vol
+        return self._load_pinned()
 
     def unpin_volume(self):
         self._pinned = None
+        self._pin_dev = None
+        self._pin_stale = False
         self._vol_staged = False
 
     def invalidate_volume(self):
@@ -267,41 +270,56 @@ class ProjectionMatrix(object):
                 self.unpin_volume()
         return _cm()
 
-    def _load_volume(self, rec):
+    def _upload_into(self, rec, buf):
+        """Device buffer holding `rec`: the DeviceArray itself, or host data uploaded into `buf` (re-allocated on a size change)."""
         be = self.backend
+        if be.is_buffer(rec):
+            return rec, buf
+        flat = np.asarray(rec).reshape(-1)
+        if buf is None or buf.size != flat.size:
+            buf = be.empty(flat.size)
+        buf.upload(flat)
+        return buf, buf
+
+    def _load_pinned(self):
+        # The pinned volume has a buffer of its own (_pin_own): an unpinned volume passed in between goes to the scratch
+        # buffer (_vol_own) and can never overwrite it.  (ADVICE r2: with one shared buffer, pin(A); call(B); call(A) evaluated
+        # A's poses on B's data.)
         self._vol_gen += 1                      # every (re)load is a new generation: nothing derived from the old one is reused
         self._vol_staged = False
         self._pin_stale = False
-        if be.is_buffer(rec):
-            self._vol_dev = rec
-            self._vol_own = False
-            return rec
-        flat = np.asarray(rec).reshape(-1)
-        if self._vol_dev is None or not self._vol_own or self._vol_dev.size != flat.size:
-            self._vol_dev = be.empty(flat.size)
-            self._vol_own = True
-        self._vol_dev.upload(flat)
+        self._pin_dev, self._pin_own = self._upload_into(self._pinned, self._pin_own)
+        return self._pin_dev
+
+    def _load_volume(self, rec):
+        """An UNPINNED volume: uploaded (host array) or taken as it is (DeviceArray) on every call; whatever the library
+        has staged for a pinned volume is no longer current afterwards."""
+        self._vol_gen += 1
+        self._vol_staged = False
+        self._vol_dev, self._vol_own = self._upload_into(rec, self._vol_own)
         return self._vol_dev
 
     def set_volume(self, rec):
         """Device buffer holding `rec` for the next proj_grad / cost_grad call: the pinned copy if `rec` is the pinned
         object, else a fresh upload (host array) / the buffer itself, to be re-staged (DeviceArray)."""
         if self._pinned is not None and rec is self._pinned:
-            if self._pin_stale:
-                return self._load_volume(rec)
-            return self._vol_dev
+            self._last_was_pinned = True
+            return self._load_pinned() if self._pin_stale else self._pin_dev
+        self._last_was_pinned = False
         return self._load_volume(rec)
 
     def pinned_call(self, fn, *args, **kw):
         """Run a proj_grad / cost_grad backend call on the volume set_volume() returned, letting the library reuse its
-        staged (zero-padded) copy only while an explicitly pinned volume is unchanged."""
+        staged (zero-padded) copy only while the explicitly pinned volume was also the one staged last and is unchanged."""
         ctx = getattr(self.backend, "ctx", None)
         if ctx is None:
             return fn(*args, **kw)
-        ctx.set_option("reuse_staged_volume", 1 if (self._vol_staged and self._pinned is not None and not self._pin_stale) else 0)
+        pinned_now = self._last_was_pinned and self._pinned is not None and not self._pin_stale
+        ctx.set_option("reuse_staged_volume", 1 if (self._vol_staged and pinned_now) else 0)
+        self._vol_staged = False
         try:
             out = fn(*args, **kw)
-            self._vol_staged = self._pinned is not None
+            self._vol_staged = pinned_now        # the library's padded copy now holds the pinned volume -- or another one
         finally:
             ctx.set_option("reuse_staged_volume", 0)
         return out

@@ -16,17 +16,29 @@ _ctx = None
 
 
 def _context(ctx=None):
+    """The caller's context, or a module-level one created on first use and closed by close_context() / at interpreter exit."""
     global _ctx
     if ctx is not None:
         return ctx
     if _ctx is None:
+        import atexit
         _ctx = _lib.Context()          # raises without a GPU: no CPU fallback
+        atexit.register(close_context)
     return _ctx
+
+
+def close_context():
+    """Destroy the module-level context (its stream, staging buffers and TV workspace)."""
+    global _ctx
+    if _ctx is not None:
+        c, _ctx = _ctx, None
+        c.close()
 
 
 def denoise_fista(im, weight=50, niter=200, eps=1.e-5, check_gap_frequency=3, ctx=None, return_info=False):
     """argmin_res 0.5*||im - res||^2 + weight*TV(res) (isotropic TV, FISTA on the dual) -- utilities/tv_denoise.py:98-170.
-    Returns the reference's `new`: the iterate of the last dual-gap check."""
+    Returns the reference's `new`: the iterate of the last dual-gap check -- as FLOAT32 for numpy input of any dtype (the
+    device computes in float32; the reference computes in the input's dtype)."""
     import ctypes
     if isinstance(im, _lib.DeviceArray):
         if len(im.shape) != 3:
@@ -43,7 +55,7 @@ def denoise_fista(im, weight=50, niter=200, eps=1.e-5, check_gap_frequency=3, ct
     it, gap = ctypes.c_int(0), ctypes.c_double(0)
     c.check(c.lib.tomo_tv_denoise_fista(c.handle, d_im.ptr, d_out.ptr, int(shape[0]), int(shape[1]), int(shape[2]), float(weight), int(niter),
                                         float(eps), int(check_gap_frequency), ctypes.byref(it), ctypes.byref(gap)))
-    out = d_out.download().astype(np.asarray(im).dtype if host and np.asarray(im).dtype.kind == 'f' else np.float32, copy=False) if host else d_out
+    out = d_out.download() if host else d_out
     return (out, it.value, gap.value) if return_info else out
 
 
