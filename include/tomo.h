@@ -137,6 +137,12 @@ TOMO_API int tomo_adjoint(tomo_ctx *ctx, const double *h_poses, int n_proj, cons
  *   kernels decline -- use tomo_adjoint then. */
 TOMO_API int tomo_adjoint_xslab_info(tomo_ctx *ctx, int *n_xtiles, int *tile_width);
 TOMO_API int tomo_adjoint_xslab(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_proj, float *d_vol, int xt0, int xt1);
+/* tomo_forward_xslab: its forward counterpart -- the partial ray sums of the x tile columns [xt0, xt1) of the same tile grid,
+ *   which read only the voxels x in [w*xt0 - 1, w*xt1] (w = tile_width): the next iteration's forward projection of a slab
+ *   starts as soon as that slab of the volume is final (all-reduced and updated) while the other slabs' all-reduces are still
+ *   on the links -- the overlap recon/sirt_mpi.py:92-110 (one blocking Allreduce per iteration) cannot have.  ADDS into d_proj
+ *   (zero it before the first slab); TOMO_ERR_UNSUPPORTED for poses the tile kernels decline (nothing launched). */
+TOMO_API int tomo_forward_xslab(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_vol, float *d_proj, int xt0, int xt1);
 
 /* tomo_backproject_voxel: the voxel-driven bilinear back-projector src/back_projection.f90:1-34
  *   (voxel_rigid_transformation + voxel_back_bilinear, src/external_back_projection.f90:1-68):
@@ -198,6 +204,11 @@ TOMO_API int tomo_vec_residual_scale(tomo_ctx *ctx, const float *d_b, const floa
                             float *d_out, int64_t n, double *h_sumsq); /* out = w*(b-ax); sumsq = ||b-ax||^2  sirt.py:60-61,69 */
 TOMO_API int tomo_vec_update(tomo_ctx *ctx, float *d_rec, const float *d_bp, const float *d_v, int64_t n,
                     int positivity, const float *d_gt, double *h_sumsq_err); /* rec += v*bp; clamp; ||gt-rec||^2  sirt.py:63-67,73 */
+/* the same update on one x slab of a pipelined iteration: no host synchronisation; ||gt-rec||^2 accumulates over the slabs on the
+ * device (zeroed when `first`) and is read back once by tomo_vec_update_acc_fetch */
+TOMO_API int tomo_vec_update_acc(tomo_ctx *ctx, float *d_rec, const float *d_bp, const float *d_v, int64_t n,
+                        int positivity, const float *d_gt, int first);
+TOMO_API int tomo_vec_update_acc_fetch(tomo_ctx *ctx, double *h_sumsq_err);
 TOMO_API int tomo_vec_axpy(tomo_ctx *ctx, float *d_y, const float *d_x, float a, int64_t n);          /* y += a*x */
 TOMO_API int tomo_vec_xpay(tomo_ctx *ctx, float *d_y, const float *d_x, float a, int64_t n);          /* y = x + a*y   cgls.py:78 */
 TOMO_API int tomo_vec_sub(tomo_ctx *ctx, float *d_out, const float *d_a, const float *d_b, int64_t n); /* out = a-b */
@@ -232,6 +243,8 @@ TOMO_API int tomo_allreduce_sum_f32(tomo_ctx *ctx, float *d_buf, int64_t n);    
  * stream; tomo_comm_join makes the compute stream wait for every asynchronous all-reduce issued before it. */
 TOMO_API int tomo_allreduce_sum_f32_async(tomo_ctx *ctx, float *d_buf, int64_t n);
 TOMO_API int tomo_comm_join(tomo_ctx *ctx);
+/* the compute stream waits for the OLDEST asynchronous all-reduce not yet waited for (issue order); no-op when none is pending */
+TOMO_API int tomo_comm_wait_next(tomo_ctx *ctx);
 TOMO_API int tomo_allreduce_sum_f64_host(tomo_ctx *ctx, double *h_vals, int n);  /* small host scalars */
 TOMO_API int tomo_allreduce_max_f64_host(tomo_ctx *ctx, double *h_vals, int n);
 

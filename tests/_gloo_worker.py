@@ -30,7 +30,26 @@ def main(out_path):
     s = sirt_mpi.SIRT(comm, geo, g["b"].copy(), angles, g["xyz"], options={"_backend": OracleBackend(shard)})
     assert np.array_equal(s.my_index, my) and s.proj_mat.shape[0] == my.size * N * N
     rec, err = s.run_main_iteration(niter=6, positivity=True)
-    n_allreduce_sirt = comm.n_vol_allreduce
+    n_allreduce_sirt, n_slab_sirt, pipelined = comm.n_vol_allreduce, comm.n_slab_allreduce, s._pipelined
+    n_fwd_whole = s.be.calls["forward"]
+    # the same run with a stand-in backend that DECLINES the tile kernels on the last rank only (an angle block holding a pose
+    # tilted beyond their domain): the decision is collective, so every rank must take the plain sequence -- one whole-volume
+    # all-reduce per iteration on every rank, no slab all-reduce anywhere -- and the result must not change
+    v0, s0 = comm.n_vol_allreduce, comm.n_slab_allreduce
+    sd = sirt_mpi.SIRT(comm, geo, g["b"].copy(), angles, g["xyz"],
+                       options={"_backend": OracleBackend(shard, declines_tiles=(comm.rank == comm.size - 1))})
+    rec_d, err_d = sd.run_main_iteration(niter=6, positivity=True)
+    declined = dict(pipelined=sd._pipelined, n_vol=comm.n_vol_allreduce - v0, n_slab=comm.n_slab_allreduce - s0)
+    # ... and with a ground truth (the error sum accumulates over the slabs on the "device") and a forced pipeline at world 1
+    comm.force_pipeline = True
+    sg = sirt_mpi.SIRT(comm, geo, g["b"].copy(), angles, g["xyz"], options={"_backend": OracleBackend(shard), "ground_truth": g["gt"] if "gt" in g else rec})
+    sg.n_pipeline_slabs = 2
+    rec_g, err_g = sg.run_main_iteration(niter=4)
+    comm.force_pipeline = False
+    sp = sirt_mpi.SIRT(comm, geo, g["b"].copy(), angles, g["xyz"], options={"_backend": OracleBackend(shard, declines_tiles=True),
+                                                                          "ground_truth": g["gt"] if "gt" in g else rec})
+    rec_p, err_p = sp.run_main_iteration(niter=4)
+    assert sg._pipelined and not sp._pipelined
     c = cgls_mpi.CGLS(comm, geo, g["b"].copy(), angles, g["xyz"], options={"_backend": OracleBackend(shard)})
     crec, cerr = c.run_main_iteration(niter=4)
     # sharded alignment: projections split over the ranks, replicated volume, one table all-reduce at the end
@@ -48,6 +67,9 @@ def main(out_path):
     ares = alignment.align_projections_sharded(comm, OracleBackend(geoa), xa, ba, phia, letters="xzab", bounds=bounds)
     if comm.rank == 0:
         np.savez(out_path, rec=rec, err=err, crec=crec, cerr=cerr, n_allreduce_sirt=n_allreduce_sirt, cor=cor,
+                 n_slab_sirt=n_slab_sirt, pipelined=pipelined, n_fwd_whole=n_fwd_whole, rec_d=rec_d, err_d=err_d,
+                 declined_pipelined=declined["pipelined"], declined_n_vol=declined["n_vol"], declined_n_slab=declined["n_slab"],
+                 rec_g=rec_g, err_g=err_g, rec_p=rec_p, err_p=err_p,
                  align_x=ares["x"], align_fun=ares["fun"], align_true=true, align_nfev=ares["nfev"])
     dist.barrier()
     dist.destroy_process_group()

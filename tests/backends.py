@@ -19,6 +19,10 @@ class Buf(object):
     def view(self, offset, n):
         return Buf(self.a[offset:offset + n], copy=False)
 
+    def zero_(self):
+        self.a[:] = 0
+        return self
+
     def download(self):
         return self.a.copy()
 
@@ -34,7 +38,10 @@ class Buf(object):
 class OracleBackend(object):
     name = "oracle(test)"
 
-    def __init__(self, geometry):
+    TILE_W = 16          # x width of a tile column of the product's tile kernels (tomo_adjoint_xslab_info)
+
+    def __init__(self, geometry, declines_tiles=False):
+        self.declines_tiles = declines_tiles       # stand-in for an angle block holding a pose the tile kernels decline
         self.geometry = geometry
         self.n_vox = int(np.prod(geometry.vox_shape))
         self.n_det = int(np.prod(geometry.det_shape))
@@ -73,6 +80,57 @@ class OracleBackend(object):
         r = orc.adjoint(self.og, proj.a, **self._kw(poses)).astype(np.float32)
         out.a[:] = out.a + r if accumulate else r
         return out
+
+    # ---- x-slab forms (tomo_adjoint_xslab / tomo_forward_xslab): tile columns of width 16 on a grid that starts at x = -1.
+    # Emulated by voxel ranges: columns [xt0, xt1) finalise -- and, here, read -- the voxels x in [16 xt0 - 1, 16 xt1 - 1) (the last
+    # column up to nx).  The slabs of a partition of the columns then sum to the whole operator, like the product's.
+    def xslab_info(self):
+        nx = int(self.geometry.vox_shape[0])
+        return (nx + 1 + self.TILE_W - 1) // self.TILE_W, self.TILE_W
+
+    def _xrange(self, xt0, xt1):
+        nx = int(self.geometry.vox_shape[0])
+        n_xt, w = self.xslab_info()
+        lo = 0 if xt0 <= 0 else min(nx, max(0, w * xt0 - 1))
+        hi = nx if xt1 >= n_xt else min(nx, max(0, w * xt1 - 1))
+        plane = self.n_vox // nx
+        return lo * plane, max(lo, hi) * plane
+
+    def _check_tiles(self):
+        if self.declines_tiles:
+            raise RuntimeError("stand-in: these poses do not take the tile kernels")
+
+    def tiles_take(self, poses, proj, vol):
+        return not self.declines_tiles
+
+    def adjoint_xslab(self, poses, proj, out, xt0, xt1):
+        self._check_tiles()
+        if xt1 <= xt0:
+            return
+        self.calls["adjoint"] += 1
+        r = orc.adjoint(self.og, proj.a, **self._kw(poses)).astype(np.float32)
+        a, b = self._xrange(xt0, xt1)
+        out.a[a:b] += r[a:b]
+
+    def forward_xslab(self, poses, vol, out, xt0, xt1):
+        self._check_tiles()
+        if xt1 <= xt0:
+            return
+        self.calls["forward"] += 1
+        a, b = self._xrange(xt0, xt1)
+        part = np.zeros_like(vol.a)
+        part[a:b] = vol.a[a:b]
+        out.a += orc.forward(self.og, part, **self._kw(poses)).astype(np.float32).ravel()
+
+    def update_acc(self, rec, bp, v, positivity=False, gt=None, first=True):
+        if first:
+            self._acc = 0.0
+        e = self.update(rec, bp, v, positivity, gt)
+        if e is not None:
+            self._acc += e
+
+    def update_acc_fetch(self):
+        return self._acc
 
     def proj_grad(self, pose, vol, proj_out, grad_out, row_order=0):
         self.calls["proj_grad"] += 1
@@ -151,6 +209,9 @@ class GlooComm(object):
         self.size = dist.get_world_size()
         self.ctx = None
         self.n_vol_allreduce = 0
+        self.n_slab_allreduce = 0
+        self.n_wait = 0
+        self.slab_sizes = []
 
     def Get_size(self):
         return self.size
@@ -164,6 +225,23 @@ class GlooComm(object):
         self.dist.all_reduce(t)
         self.n_vol_allreduce += 1
         return buf
+
+    # the asynchronous forms: gloo on host buffers is synchronous, so "start" does the all-reduce and the waits are no-ops; what
+    # the tests see is the SEQUENCE of collectives (gloo fails on mismatched sizes / hangs on mismatched counts) and the counts
+    def allreduce_sum_async(self, buf):
+        import torch
+        t = torch.from_numpy(buf.a)
+        if t.numel():
+            self.dist.all_reduce(t)
+        self.n_slab_allreduce += 1
+        self.slab_sizes.append(int(buf.size))
+        return buf
+
+    def wait_next(self):
+        self.n_wait += 1
+
+    def join(self):
+        pass
 
     def allreduce_scalar(self, v):
         import torch

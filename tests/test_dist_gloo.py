@@ -41,8 +41,21 @@ def test_sharded_solvers_match_unsharded(tmp_path):
     assert np.allclose(two["err"], one["err"], rtol=1e-5)
     assert rel_max(two["crec"], one["crec"]) < 1e-4
     assert np.allclose(two["cerr"], one["cerr"], rtol=1e-4)
-    # one all-reduce of V at init (recon/sirt_mpi.py:68) + one per iteration (:103)
-    assert int(two["n_allreduce_sirt"]) == 1 + len(two["err"])
+    # world 2 pipelines (decided collectively at init): one whole-volume all-reduce of V at init (recon/sirt_mpi.py:68), then per
+    # iteration one all-reduce per x slab (32^3: 3 tile columns -> 3 slabs) whose sizes add up to the volume (:103); the forward
+    # projection of iterations 2.. is made slab by slab behind the update (2 whole forwards: W at init and iteration 1)
+    n_it = len(two["err"])
+    assert bool(two["pipelined"]) and not bool(one["pipelined"])
+    assert int(two["n_allreduce_sirt"]) == 1 and int(two["n_slab_sirt"]) == 3 * n_it
+    assert int(one["n_allreduce_sirt"]) == 1 + len(one["err"]) and int(one["n_slab_sirt"]) == 0
+    # a rank whose block declines the tile kernels: EVERY rank takes the plain sequence (rank-uniform collectives), same result
+    assert not bool(two["declined_pipelined"]) and int(two["declined_n_slab"]) == 0 and int(two["declined_n_vol"]) == 1 + n_it
+    assert rel_max(two["rec_d"], two["rec"]) < 1e-5 and np.allclose(two["err_d"], two["err"], rtol=1e-5)
+    assert rel_max(one["rec_d"], one["rec"]) < 1e-6
+    # pipelined with a ground truth (error accumulated over the slabs) == plain, at world 1 (forced) and world 2
+    for w in (one, two):
+        assert rel_max(w["rec_g"], w["rec_p"]) < 1e-5 and np.allclose(w["err_g"], w["err_p"], rtol=1e-5)
+    assert rel_max(two["rec_g"], one["rec_g"]) < 1e-5
     # sharded alignment: every rank aligns its block, the gathered table is the unsharded answer and recovers the poses
     assert np.allclose(two["align_x"], one["align_x"], atol=1e-9) and np.array_equal(two["align_nfev"], one["align_nfev"])
     assert np.allclose(two["align_x"], two["align_true"], atol=2e-4) and np.all(two["align_fun"] < 1e-6)

@@ -207,6 +207,46 @@ def test_pipelined_allreduce_path_matches_plain(shepp32):
         assert rel_max(res[True][0], res[False][0]) < 2e-6 and np.allclose(res[True][1], res[False][1], rtol=1e-6)
     be = HipBackend(geo, ctx=ctx)
     assert be.xslab_info() == (3, 16)
+    # round 3: the NEXT iteration's forward projection is made slab by slab behind the update (tomo_forward_xslab, tomo_comm_wait_next).
+    # A ragged volume with 6 tile columns, flat and tilted poses, positivity and a ground truth (the error sum accumulates over the
+    # slabs on the device); per iteration every slab's all-reduce is waited for once and iterations 2.. launch no whole forward.
+    from oracle import oracle as orc
+    shape, ndet, n_proj = (80, 40, 48), (72, 56), 12
+    rng = np.random.default_rng(11)
+    x = np.zeros(shape, np.float32)
+    x[10:70, 6:34, 8:40] = rng.uniform(0.2, 1.0, (60, 28, 32)).astype(np.float32)
+    phi = np.linspace(0.05, np.pi - 0.05, n_proj)
+    from tomography_alignment_amd.utilities.geometry import Geometry
+    geo2 = Geometry(n_proj, np.array(shape), np.ones(3), np.array(ndet), np.ones(2))
+    og = orc.Geo(n_proj, np.array(shape), np.ones(3), np.array(ndet), np.ones(2))
+    for tilt in (0.0, 1.0):
+        alpha, beta = np.deg2rad(tilt * rng.uniform(-1.5, 1.5, n_proj)), np.deg2rad(tilt * rng.uniform(-1.5, 1.5, n_proj))
+        xyz = np.zeros((n_proj, 3))
+        xyz[:, 0], xyz[:, 2] = rng.uniform(-2, 2, n_proj), rng.uniform(-2, 2, n_proj)
+        b = orc.forward(og, x, alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz).astype(np.float32)
+        ang = np.array([phi, alpha, beta]).T
+        res = {}
+        for force, slabs in ((False, 8), (True, 8), (True, 4), (True, 2)):
+            comm.force_pipeline = force
+            s = sirt_mpi.SIRT(comm, geo2, b.copy(), ang, xyz, options={"_backend": HipBackend(geo2, ctx=ctx), "ground_truth": x})
+            s.n_pipeline_slabs = slabs
+            assert s._pipelined == force
+            ctx.profile_reset()
+            ctx.profile_enable(True)
+            res[(force, slabs)] = s.run_main_iteration(niter=5, positivity=True)
+            ctx.profile_enable(False)
+            n_wait = ctx.profile_get("comm_join_wait")[0]
+            n_fwd = sum(ctx.profile_get(k)[0] for k in ("k_fwd_tile_flat", "k_fwd_tile"))
+            if force:
+                n_slab = min(slabs, 6)
+                assert n_wait == 5 * n_slab, (n_wait, n_slab)          # each slab's all-reduce waited for exactly once per iteration
+                assert n_fwd == 1 + 4 * n_slab, (n_fwd, n_slab)        # iteration 1 whole; 2..5 slab by slab; none made ahead after the last
+            else:
+                assert n_wait == 0 and n_fwd == 5
+        ref = res[(False, 8)]
+        for key, got in res.items():
+            assert rel_max(got[0], ref[0]) < 2e-6 and np.allclose(got[1], ref[1], rtol=1e-6), (tilt, key)
+        assert ref[1][-1] < ref[1][0]
     comm.close()
 
 

@@ -57,6 +57,7 @@ SIGNATURES = {
     "tomo_adjoint": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp, ctypes.c_int]),
     "tomo_adjoint_xslab_info": (ctypes.c_int, [_c_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "tomo_adjoint_xslab": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int]),
+    "tomo_forward_xslab": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int]),
     "tomo_backproject_voxel": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp]),
     "tomo_proj_grad": (ctypes.c_int, [_c_vp, _c_dp, _c_vp, _c_vp, _c_vp, ctypes.c_int]),
     "tomo_cost_grad": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp, _c_dp, _c_dp, _c_vp]),
@@ -70,6 +71,8 @@ SIGNATURES = {
     "tomo_vec_fill": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, ctypes.c_float]),
     "tomo_vec_residual_scale": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_dp]),
     "tomo_vec_update": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_vp, _c_dp]),
+    "tomo_vec_update_acc": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_vp, ctypes.c_int]),
+    "tomo_vec_update_acc_fetch": (ctypes.c_int, [_c_vp, _c_dp]),
     "tomo_vec_axpy": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_float, _c_i64]),
     "tomo_vec_xpay": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_float, _c_i64]),
     "tomo_vec_sub": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64]),
@@ -86,6 +89,7 @@ SIGNATURES = {
     "tomo_allreduce_sum_f32": (ctypes.c_int, [_c_vp, _c_vp, _c_i64]),
     "tomo_allreduce_sum_f32_async": (ctypes.c_int, [_c_vp, _c_vp, _c_i64]),
     "tomo_comm_join": (ctypes.c_int, [_c_vp]),
+    "tomo_comm_wait_next": (ctypes.c_int, [_c_vp]),
     "tomo_allreduce_sum_f64_host": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int]),
     "tomo_allreduce_max_f64_host": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int]),
     "tomo_timer_start": (ctypes.c_int, [_c_vp]),

@@ -82,6 +82,23 @@ class HipBackend(object):
         self._geom()
         self.ctx.check(self.lib.tomo_adjoint_xslab(self.ctx.handle, _lib.dptr(poses), poses.shape[0], proj.ptr, out.ptr, int(xt0), int(xt1)))
 
+    def forward_xslab(self, poses, vol, out, xt0, xt1):
+        """The partial ray sums of the x tile columns [xt0, xt1) (they read only the voxels x in [w*xt0 - 1, w*xt1]); ADDS into
+        `out` (zero it first).  Raises TomoError for poses the tile kernels decline."""
+        self._geom()
+        self.ctx.check(self.lib.tomo_forward_xslab(self.ctx.handle, _lib.dptr(poses), poses.shape[0], vol.ptr, out.ptr, int(xt0), int(xt1)))
+
+    def tiles_take(self, poses, proj, vol):
+        """True when every pose of `poses` takes the tile kernels, i.e. the x-slab forms above exist for them (an empty
+        column range launches nothing)."""
+        try:
+            self.adjoint_xslab(poses, proj, vol, 0, 0)
+            return True
+        except _lib.TomoError as e:
+            if "do not take the tile kernels" not in str(e):
+                raise
+            return False
+
     def backproject_voxel(self, poses, det, out):
         self._geom()
         n = poses.shape[0]
@@ -172,6 +189,17 @@ class HipBackend(object):
         self.ctx.check(self.lib.tomo_vec_update(self.ctx.handle, rec.ptr, bp.ptr, v.ptr if v is not None else None, rec.size,
                                                 1 if positivity else 0, gt.ptr if gt is not None else None, ctypes.byref(s)))
         return s.value if gt is not None else None
+
+    def update_acc(self, rec, bp, v, positivity=False, gt=None, first=True):
+        """`update` on one x slab of a pipelined iteration: nothing comes back to the host; ||gt - rec||^2 accumulates on the
+        device across the slabs (restarted when `first`) until update_acc_fetch()."""
+        self.ctx.check(self.lib.tomo_vec_update_acc(self.ctx.handle, rec.ptr, bp.ptr, v.ptr if v is not None else None, rec.size,
+                                                    1 if positivity else 0, gt.ptr if gt is not None else None, 1 if first else 0))
+
+    def update_acc_fetch(self):
+        s = ctypes.c_double(0)
+        self.ctx.check(self.lib.tomo_vec_update_acc_fetch(self.ctx.handle, ctypes.byref(s)))
+        return s.value
 
     def axpy(self, y, x, a):
         self.ctx.check(self.lib.tomo_vec_axpy(self.ctx.handle, y.ptr, x.ptr, float(a), y.size))

@@ -209,6 +209,10 @@ class RcclComm(object):
     def join(self):
         self.ctx.check(self.ctx.lib.tomo_comm_join(self.ctx.handle))
 
+    def wait_next(self):
+        """The compute stream waits for the oldest allreduce_sum_async it has not waited for yet (issue order)."""
+        self.ctx.check(self.ctx.lib.tomo_comm_wait_next(self.ctx.handle))
+
     def allreduce_scalar(self, v):
         a = np.array([v], np.float64)
         self.ctx.check(self.ctx.lib.tomo_allreduce_sum_f64_host(self.ctx.handle, _lib.dptr(a), 1))

@@ -543,14 +543,14 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
 #define FZ_WAVES 16
 template <int NZT>
 __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
-                                                              const float *__restrict__ vol, TomoGeomC g)
+                                                              const float *__restrict__ vol, TomoGeomC g, int tile_x0)
 {
     // the images of the NZT stacked tiles are INTERLEAVED per (x, y) cell: [x][y][tile][64 planes] -- every corner of every image of a
     // sample then lies within ds_read2st64_b32's offset range (units of 256 B, < 256) of ONE address register
     __shared__ float img[ALX * ALY * NZT * FLZ];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int z0 = -1 + (int)blockIdx.x * (NZT * FTZ), y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + (int)blockIdx.z * ATX;
+    const int z0 = -1 + (int)blockIdx.x * (NZT * FTZ), y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + ((int)blockIdx.z + tile_x0) * ATX;
     bool live[NZT];
     bool any_live = false;
 #pragma unroll

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <deque>
 #include <map>
 #include <string>
 #include <vector>
@@ -73,6 +74,8 @@ struct tomo_ctx {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_compute = nullptr, ev_comm = nullptr;
     bool comm_pending = false;
+    std::deque<hipEvent_t> comm_done;    // one event per asynchronous all-reduce the compute stream has not yet waited for (issue order)
+    std::vector<hipEvent_t> comm_ev_pool;
     int n_ranks = 1, rank = 0;
     std::string err;
 };

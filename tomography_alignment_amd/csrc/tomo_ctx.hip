@@ -55,6 +55,8 @@ extern "C" int tomo_ctx_destroy(tomo_ctx *c)
     if (c->ev_compute) (void)hipEventDestroy(c->ev_compute);
     if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    for (auto e : c->comm_done) (void)hipEventDestroy(e);
+    for (auto e : c->comm_ev_pool) (void)hipEventDestroy(e);
     for (auto &p : c->pending) { c->ev_pool.push_back(p.e0); c->ev_pool.push_back(p.e1); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->d_volpad) (void)hipFree(c->d_volpad);
@@ -494,6 +496,32 @@ extern "C" int tomo_vec_update(tomo_ctx *ctx, float *rec, const float *bp, const
     return (gt && h_sumsq_err) ? red_fetch(ctx, h_sumsq_err) : TOMO_OK;
 }
 
+// The update of recon/sirt.py:63-67,73 applied to ONE x slab of a pipelined iteration: no host synchronisation; the error sum
+// accumulates across the slabs in a device scalar (zeroed when `first`), fetched once by tomo_vec_update_acc_fetch.
+#define TOMO_RED_UPDATE_ACC 2      // slot of d_red (0: one-shot reductions, 4: the tile adjoint's abs-max, 8..: host all-reduces)
+extern "C" int tomo_vec_update_acc(tomo_ctx *ctx, float *rec, const float *bp, const float *v, int64_t n, int positivity, const float *gt, int first)
+{
+    if (!ctx) return tomo_fail(nullptr, TOMO_ERR_ARG, "null ctx");
+    if (n < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "negative n");
+    int rc = tomo_ensure_red(ctx, 8);
+    if (rc) return rc;
+    if (first) TOMO_HIP(ctx, hipMemsetAsync(ctx->d_red + TOMO_RED_UPDATE_ACC, 0, sizeof(double), ctx->stream));
+    if (n == 0) return TOMO_OK;
+    TOMO_LAUNCH(ctx, "k_update", k_update, dim3(vec_grid(n)), dim3(256), 0, rec, bp, v, n, positivity, gt, ctx->d_red + TOMO_RED_UPDATE_ACC);
+    return TOMO_OK;
+}
+
+extern "C" int tomo_vec_update_acc_fetch(tomo_ctx *ctx, double *h_sumsq_err)
+{
+    if (!ctx || !h_sumsq_err) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
+    int rc = tomo_ensure_red(ctx, 8);
+    if (rc) return rc;
+    TOMO_HIP(ctx, hipMemcpyAsync(ctx->h_red + TOMO_RED_UPDATE_ACC, ctx->d_red + TOMO_RED_UPDATE_ACC, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *h_sumsq_err = ctx->h_red[TOMO_RED_UPDATE_ACC];
+    return TOMO_OK;
+}
+
 extern "C" int tomo_vec_dot(tomo_ctx *ctx, const float *a, const float *b, int64_t n, double *h_dot)
 {
     if (!h_dot) return tomo_fail(ctx, TOMO_ERR_ARG, "null out");
@@ -647,6 +675,30 @@ extern "C" int tomo_allreduce_sum_f32_async(tomo_ctx *ctx, float *d_buf, int64_t
     if (r != ncclSuccess) return tomo_fail(ctx, TOMO_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
     TOMO_HIP(ctx, hipEventRecord(ctx->ev_comm, ctx->comm_stream));
     ctx->comm_pending = true;
+    // ... and an event of its own, for callers that consume the all-reduces one by one (tomo_comm_wait_next)
+    hipEvent_t e = nullptr;
+    if (!ctx->comm_ev_pool.empty()) { e = ctx->comm_ev_pool.back(); ctx->comm_ev_pool.pop_back(); }
+    else TOMO_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    TOMO_HIP(ctx, hipEventRecord(e, ctx->comm_stream));
+    ctx->comm_done.push_back(e);
+    return TOMO_OK;
+}
+
+// The compute stream waits for the OLDEST asynchronous all-reduce it has not waited for yet (issue order).  With this a caller
+// consumes the x slabs of a pipelined update one by one -- slab s is updated, and the next iteration's forward projection of that
+// slab started, while the all-reduces of the later slabs are still on the links (recon/sirt_mpi.py).  No-op when none is pending.
+extern "C" int tomo_comm_wait_next(tomo_ctx *ctx)
+{
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    if (ctx->comm_done.empty()) return TOMO_OK;
+    hipEvent_t e = ctx->comm_done.front();
+    ctx->comm_done.pop_front();
+    tomo_prof_begin(ctx, "comm_join_wait");                  // the same record as tomo_comm_join: exposed communication, summed per step
+    hipError_t r = hipStreamWaitEvent(ctx->stream, e, 0);
+    tomo_prof_end(ctx);
+    ctx->comm_ev_pool.push_back(e);                          // a wait already queued keeps the state the event had when it was queued
+    if (r != hipSuccess) return tomo_fail(ctx, TOMO_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(r));
+    if (ctx->comm_done.empty()) ctx->comm_pending = false;
     return TOMO_OK;
 }
 
@@ -661,6 +713,8 @@ extern "C" int tomo_comm_join(tomo_ctx *ctx)
         tomo_prof_end(ctx);
         ctx->comm_pending = false;
     }
+    for (auto e : ctx->comm_done) ctx->comm_ev_pool.push_back(e);
+    ctx->comm_done.clear();
     return TOMO_OK;
 }
 

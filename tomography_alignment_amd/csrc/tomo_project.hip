@@ -213,6 +213,43 @@ static int stage_tile_consts(tomo_ctx *ctx, const double *h_poses, int n_proj, b
 
 static inline dim3 tile_grid(const TomoGeomC &g, int tz = ATZ) { return dim3((g.nz + 1 + tz - 1) / tz, (g.ny + 1 + ATY - 1) / ATY, (g.nx + 1 + ATX - 1) / ATX); }
 
+// Tile forward restricted to the x tile columns [xt0, xt1): ADDS the partial ray sums of those tiles into d_proj (the caller
+// zeroes it).  *done = false when the poses do not qualify for the tile kernels (nothing launched).
+static int forward_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_vol, float *d_proj, int xt0, int xt1, bool *done)
+{
+    const TomoGeomC &g = ctx->g;
+    *done = false;
+    if (ctx->fwd_variant != 3 || n_proj <= 0) return TOMO_OK;
+    dim3 grid = tile_grid(g);
+    if (grid.y > 65535 || grid.z > 65535) return TOMO_OK;
+    bool ok = false;
+    double wb = 2.0;
+    int n_flat = 0;
+    int rc = stage_tile_consts(ctx, h_poses, n_proj, &ok, &wb, &n_flat);
+    if (rc) return rc;
+    if (!ok) return TOMO_OK;
+    *done = true;
+    xt0 = std::max(xt0, 0);
+    xt1 = std::min(xt1, (int)grid.z);
+    if (xt1 <= xt0) return TOMO_OK;
+    grid.z = (unsigned)(xt1 - xt0);
+    const AdjC *d_c = (const AdjC *)ctx->d_stage;
+    if (n_flat > 0) {
+        dim3 fg = tile_grid(g, FTZ);
+        fg.z = grid.z;
+        if (fg.x >= 2 && ctx->fwd_flat_ztiles >= 2)         // two z-adjacent tiles per work-group share the per-row set-up
+            TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_fwd_flat_z<2>, dim3((fg.x + 1) / 2, fg.y, fg.z), dim3(FZ_WAVES * 64), 0, d_c, n_flat,
+                        d_proj, d_vol, g, xt0);
+        else
+            TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_tile_flat<true>, fg, dim3(ADJ_WAVES * 64), 0, d_c, n_flat, d_proj,
+                        (float *)d_vol, g, (const unsigned *)nullptr, 1.f, xt0);
+    }
+    if (n_proj > n_flat)
+        TOMO_LAUNCH(ctx, "k_fwd_tile", k_tile<true>, grid, dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, d_proj, (float *)d_vol,
+                    g, (const unsigned *)nullptr, 1.f, xt0);
+    return TOMO_OK;
+}
+
 extern "C" int tomo_forward(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_vol, float *d_proj)
 {
     TOMO_NEED_GEOM(ctx);
@@ -222,31 +259,12 @@ extern "C" int tomo_forward(tomo_ctx *ctx, const double *h_poses, int n_proj, co
     const size_t n_det = (size_t)g.ndx * g.ndz;
     int rc;
     if (ctx->fwd_variant == 3) {
-        const dim3 grid = tile_grid(g);
-        bool ok = false;
-        double wb = 2.0;
-        int n_flat = 0;
-        if (grid.y <= 65535 && grid.z <= 65535) {
-            rc = stage_tile_consts(ctx, h_poses, n_proj, &ok, &wb, &n_flat);
-            if (rc) return rc;
-        }
-        if (ok) {
-            const AdjC *d_c = (const AdjC *)ctx->d_stage;
-            TOMO_HIP(ctx, hipMemsetAsync(d_proj, 0, n_det * (size_t)n_proj * sizeof(float), ctx->stream));
-            if (n_flat > 0) {
-                const dim3 fg = tile_grid(g, FTZ);
-                if (fg.x >= 2 && ctx->fwd_flat_ztiles >= 2)         // two z-adjacent tiles per work-group share the per-row set-up
-                    TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_fwd_flat_z<2>, dim3((fg.x + 1) / 2, fg.y, fg.z), dim3(FZ_WAVES * 64), 0, d_c, n_flat,
-                                d_proj, d_vol, g);
-                else
-                    TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_tile_flat<true>, fg, dim3(ADJ_WAVES * 64), 0, d_c, n_flat, d_proj,
-                                (float *)d_vol, g, (const unsigned *)nullptr, 1.f, 0);
-            }
-            if (n_proj > n_flat)
-                TOMO_LAUNCH(ctx, "k_fwd_tile", k_tile<true>, grid, dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, d_proj, (float *)d_vol,
-                            g, (const unsigned *)nullptr, 1.f, 0);
-            return TOMO_OK;
-        }
+        // the tile kernels add into d_proj: zero it first; if the poses turn out not to qualify, the ray-driven path overwrites anyway
+        TOMO_HIP(ctx, hipMemsetAsync(d_proj, 0, n_det * (size_t)n_proj * sizeof(float), ctx->stream));
+        bool done = false;
+        rc = forward_tiles(ctx, h_poses, n_proj, d_vol, d_proj, 0, INT_MAX, &done);
+        if (rc) return rc;
+        if (done) return TOMO_OK;
     }
     rc = stage_volume(ctx, d_vol);
     if (rc) return rc;
@@ -261,6 +279,20 @@ extern "C" int tomo_forward(tomo_ctx *ctx, const double *h_poses, int n_proj, co
         else
             TOMO_LAUNCH(ctx, "k_fwd_v2", k_fwd_v2, ray_grid(g, np), dim3(256), 0, d_pc, ctx->d_volpad, out, g);
     }
+    return TOMO_OK;
+}
+
+// x-slab form of the forward projection, the counterpart of tomo_adjoint_xslab: the tile columns [xt0, xt1) read only the voxels
+// x in [ATX*xt0 - 1, ATX*xt1] (clipped to the volume), so a sharded solver can start them as soon as that range of the volume is
+// final while the all-reduces of the other slabs are still in flight.  ADDS into d_proj (zero it before the first slab).
+extern "C" int tomo_forward_xslab(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_vol, float *d_proj, int xt0, int xt1)
+{
+    TOMO_NEED_GEOM(ctx);
+    if (!h_poses || !d_vol || !d_proj || n_proj < 0 || xt0 < 0 || xt1 < xt0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_forward_xslab: bad args");
+    bool done = false;
+    int rc = forward_tiles(ctx, h_poses, n_proj, d_vol, d_proj, xt0, xt1, &done);
+    if (rc) return rc;
+    if (!done) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "tomo_forward_xslab: these poses do not take the tile kernels");
     return TOMO_OK;
 }
 

@@ -131,10 +131,10 @@ class SIRT(object):
         convergence = np.zeros((niter,))
         t_start = time.time()
         while k < niter and not stop:
-            self.proj_mat.apply(self.d_rec, self.d_ax)                                  # sirt.py:59
+            self._forward()                                                             # sirt.py:59
             sumsq = be.residual_scale(self.d_b, self.d_ax, self.d_W, self.d_res)        # :60-61 (W * res) and :69
             self._backproject_scaled()                                                  # :61,63 ; sirt_mpi.py:98-103
-            err = be.update(self.d_rec, self.d_bp, None, positivity, self.d_gt)         # :64-67,73
+            err = self._update(positivity, last=(k + 1 >= niter))                       # :64-67,73
             convergence[k] = np.sqrt(self._allreduce_scalar(sumsq))                     # :69 ; sirt_mpi.py:110
             rms_error[k] = convergence[k] / norm_factor if self.d_gt is None else np.sqrt(err) / norm_factor
             if k > self._stop_after and rms_error[k] > rms_error[k - 1]:
@@ -148,6 +148,14 @@ class SIRT(object):
         self.rms_error = rms_error
         self.convergence = convergence
         return k, rms_error[:k]
+
+    def _forward(self):
+        """d_ax = A d_rec."""
+        self.proj_mat.apply(self.d_rec, self.d_ax)
+
+    def _update(self, positivity, last=False):
+        """rec += d_bp (already scaled by V), clamp; returns ||gt - rec||^2 when a ground truth is given."""
+        return self.be.update(self.d_rec, self.d_bp, None, positivity, self.d_gt)
 
     def _backproject_scaled(self):
         """d_bp = V * A^T d_res, summed over the angle shards."""
