@@ -45,6 +45,8 @@ LDS_PEAK_GBS = N_CU * 128 * CLK_GHZ              # 128 B/clk/CU for ds_read_b32 
 # ... and what tools/issue_bench.hip measured on this chip with every CU issuing (clock as held under that load): the
 # practical ceilings, quoted beside the spec-derived ones
 VALU_MEASURED_GINSTR = 570.0  # v_fma_f32 573, v_readlane 519, v_pk_fma_f32 475, v_add_u32 773 G wave-instr/s (profiles/round2_issue_bench.log)
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md chip-level parameters
+ATOMIC_PEAK_GBS = 1300.0          # global float atomics execute at the memory side at ~1.3 TB/s of added bytes chip-wide (MI355X_MICROARCH.md)
 LDS_MEASURED_GINSTR2 = 142.0  # ds_read2_b32 / ds_read2st64_b32 / ds_add_u32 / ds_write_b32: 142 G wave-instr/s = 72.7 TB/s at 512 B each
 
 
@@ -132,6 +134,7 @@ def main():
     ap.add_argument("--dense", action="store_true", help="headline on a volume without zero regions (no all-zero tile exits)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-align", action="store_true", help="skip the alignment-gradient evals/s side measurement (config 5)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the align_rigid end-to-end side measurement (config 5: SIRT + one alignment pass)")
     ap.add_argument("--no-tilted", action="store_true", help="skip the tilted-pose SIRT side measurement")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-volume SIRT side measurement")
     ap.add_argument("--force-sharded", action="store_true",
@@ -260,7 +263,7 @@ def main():
     roofline = None
     if cands:
         step_ms, name, alg = max(cands)
-        roofline = make_roofline(name, step_ms, kern[name]["launches_per_step"], alg, key)
+        roofline = make_roofline(name, step_ms, kern[name]["launches_per_step"], alg, key, n_loc * float(N) ** 3, 4.0 * n_loc * n_det)
     extra = {}
     if fwd_name:
         extra["forward_alg_GBps"] = round(alg_fwd / (kern[fwd_name]["ms_per_step"] * 1e-3) / 1e9, 1)
@@ -269,7 +272,7 @@ def main():
     # the other projector kernel, priced the same way (secondary)
     if roofline is not None and len(cands) == 2:
         o_ms, o_name, o_alg = min(cands)
-        extra["roofline_other_kernel"] = make_roofline(o_name, o_ms, kern[o_name]["launches_per_step"], o_alg, key)
+        extra["roofline_other_kernel"] = make_roofline(o_name, o_ms, kern[o_name]["launches_per_step"], o_alg, key, n_loc * float(N) ** 3, 4.0 * n_loc * n_det)
 
     its = args.steps / elapsed
     out = {
@@ -331,6 +334,9 @@ def main():
     if not args.no_align:
         del solver
         out["alignment_gradient"] = align_rate(comm, ctx, rank, world, N=min(512, max(32, N // 2)), n_proj=720 if N >= 1024 else max(8, n_proj // 2))
+    if not args.no_align and world == 1 and not args.no_e2e:
+        # config 5 end to end (VERDICT r2 "missing" #2): one outer iteration of examples/align_rigid.py's loop
+        out["align_rigid_e2e"] = align_rigid_e2e(ctx, N=min(512, max(32, N // 2)), n_proj=720 if N >= 1024 else max(8, n_proj // 2))
     if roofline is not None:
         roofline["measured_d2d_copy_GBps"] = copy_probe(ctx, be)        # read + write of a 2 GiB hipMemcpy D2D, same run
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -343,7 +349,7 @@ def main():
         comm.close()
 
 
-def make_roofline(name, ms_per_step, launches_per_step, alg_bytes_per_pass, key):
+def make_roofline(name, ms_per_step, launches_per_step, alg_bytes_per_pass, key, useful_samples_per_pass=None, useful_sino_bytes=None):
     """Utilisation of every unit that could bound `name`, from counted work per launch (committed rocprofv3 PMC passes of this
     very command, profiles/sq_counters.json + profiles/pmc_traffic.json) and the live launch time; `bound` = the busiest unit.
     Without counters for this workload: the algorithmic-HBM figure only, flagged `counters: null`."""
@@ -353,22 +359,49 @@ def make_roofline(name, ms_per_step, launches_per_step, alg_bytes_per_pass, key)
          "hbm_algorithmic": {"bytes_per_launch": alg_bytes_per_pass / launches_per_step, "GBps": round(alg_gbs, 1), "frac_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4),
                              "note": "SURVEY 8d byte model (volume re-read per angle); the LDS-tile kernels read the volume once per call, so this is not a roofline for them"},
          "traffic": None, "counters": None}
-    sq, pmc = None, None
+    sq, pmc, write_bytes = None, None, None
+    # Committed counters are used only for THIS workload (key) taken on THESE kernel sources (src_hash over csrc/*): counts of an
+    # older kernel divided by the live time of a newer one would be a silent mix.
+    from tomography_alignment_amd import _lib
+    live_hash = _lib.kernel_source_hash()
+    stale = []
     try:
         j = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))
         if j.get("key") == key and name in j["kernels"]:
-            sq = j["kernels"][name]
-            r["counters"] = {"source": "profiles/sq_counters.json (%s)" % j.get("source", ""), "per_pass": sq}
+            if j.get("src_hash") == live_hash:
+                sq = j["kernels"][name]
+                r["counters"] = {"source": "profiles/sq_counters.json (%s, kernel sources %s)" % (j.get("source", ""), live_hash), "per_pass": sq}
+            else:
+                stale.append("profiles/sq_counters.json (%s) was taken on kernel sources %s, this run has %s" % (j.get("source", ""), j.get("src_hash"), live_hash))
     except (OSError, ValueError, KeyError):
         pass
     try:
         j = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if j.get("key") == key and name in j["kernels"]:
-            pmc = j["kernels"][name]["hbm_bytes_per_launch"]
-            r["traffic"] = pmc / launches_per_step
-            r["traffic_source"] = "profiles/pmc_traffic.json (%s)" % j.get("source", "")
+            if j.get("src_hash") == live_hash:
+                pmc = j["kernels"][name]["hbm_bytes_per_launch"]
+                write_bytes = j["kernels"][name].get("write_kb", 0.0) * 1024.0
+                r["traffic"] = pmc / launches_per_step
+                r["traffic_source"] = "profiles/pmc_traffic.json (%s, kernel sources %s)" % (j.get("source", ""), live_hash)
+            else:
+                stale.append("profiles/pmc_traffic.json (%s) was taken on kernel sources %s, this run has %s" % (j.get("source", ""), j.get("src_hash"), live_hash))
     except (OSError, ValueError, KeyError):
         pass
+    if stale:
+        r["stale_counters_refused"] = stale
+    # useful arithmetic: every in-volume ray sample needs the four x,y-corner FMAs of its plane pair's bilinear weights = 8 flop in
+    # the regrouped (flat) form -- n_samples = n_angles * N^3 per pass (a unit lattice has one sample per voxel volume) -- against
+    # the fp32 vector peak.  Independent of how many instructions the kernel spends per sample: the busy fractions below say how
+    # full the pipes are, this says how much of what they do is the interpolation itself.
+    if useful_samples_per_pass:
+        r["useful_flop_frac"] = round(8.0 * useful_samples_per_pass / t / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4)
+        r["useful_flop"] = {"samples_per_pass": useful_samples_per_pass, "flop_per_sample": 8, "TFLOPs": round(8.0 * useful_samples_per_pass / t / 1e12, 2),
+                            "peak_TFLOPs": FP32_VECTOR_PEAK_TFLOPS}
+    if write_bytes is not None and name.startswith("k_fwd"):
+        # the forward kernels' stores are all float atomics into the sinogram (WRITE_SIZE is exact for them, MI355X_MICROARCH.md)
+        r["atomics_frac"] = round(write_bytes / t / 1e9 / ATOMIC_PEAK_GBS, 4)
+        r["atomics"] = {"bytes_per_pass": write_bytes, "GBps": round(write_bytes / t / 1e9, 1), "memory_side_ceiling_GBps": ATOMIC_PEAK_GBS,
+                        "amplification_vs_sinogram": round(write_bytes / max(1.0, useful_sino_bytes), 1) if useful_sino_bytes else None}
     util = {}
     if pmc is not None:
         util["hbm"] = (pmc / t / 1e9, HBM_PEAK_GBS, "GB/s")
@@ -466,6 +499,56 @@ def align_rate(comm, ctx, rank, world, N=512, n_proj=720, passes=3):
     return out
 
 
+def align_rigid_e2e(ctx, N=512, n_proj=720, sirt_iters=10):
+    """Side measurement (not `value`): BASELINE config 5 END TO END -- one outer iteration of the reference's examples/align_rigid.py:27-59
+    loop on N^3 x n_proj with +-2 deg / +-5 px pose errors (default_rng(5), as align_rate): `sirt_iters` SIRT iterations with positivity
+    at the nominal poses (device-resident solver), then ONE lock-step alignment pass (every projection's scipy L-BFGS-B on cost_xzab /
+    gradient_xzab from a zero start, bounds +-6 px / +-0.05 rad, one fused cost+gradient launch per round of evaluations).  Wall
+    times include the host side (scipy, thread scheduling, staging); kernel times are HIP-event sums."""
+    from tomography_alignment_amd import _lib
+    from tomography_alignment_amd.backend import HipBackend
+    from tomography_alignment_amd.examples import align_rigid
+    from tomography_alignment_amd.utilities.geometry import Geometry
+    from tomography_alignment_amd.utilities.generate_phantom import SHEPP_LOGAN
+    rng = np.random.default_rng(5)
+    phi = np.linspace(0., np.pi, n_proj)
+    alpha, beta = np.deg2rad(rng.uniform(-2, 2, n_proj)), np.deg2rad(rng.uniform(-2, 2, n_proj))
+    xyz = np.zeros((n_proj, 3))
+    xyz[:, 0], xyz[:, 2] = rng.uniform(-5, 5, n_proj), rng.uniform(-5, 5, n_proj)
+    geo = Geometry(n_proj, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
+    be = HipBackend(geo, ctx=ctx)
+    vol = be.phantom(be.empty(N ** 3), (N, N, N), SHEPP_LOGAN)
+    d_b = be.forward(_lib.poses_array(phi, alpha, beta, xyz, np.zeros(3)), vol, be.empty(n_proj * N * N))
+    data = dict(projections=d_b.download().reshape(n_proj, N, N), phi=phi, alpha=alpha, beta=beta, xyz=xyz, phantom=vol.download().reshape(N, N, N))
+    del d_b, vol
+    names = ("k_fwd_tile", "k_fwd_tile_flat", "k_adj_tile", "k_adj_tile_flat", "k_adj_gather_flat", "k_cost_grad", "k_pad", "k_box", "k_residual_scale", "k_update", "k_vec", "k_absmax")
+    ctx.sync()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    _, a_rec, b_rec, xyz_rec, hist = align_rigid.run(data, n_outer=1, sirt_iters=sirt_iters, bounds=((-6., 6.), (-6., 6.), (-0.05, 0.05), (-0.05, 0.05)),
+                                                     verbose=False, backend=be)
+    ctx.sync()
+    wall = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    kms = {}
+    for nm in names:
+        n, ms = ctx.profile_get(nm)
+        if n:
+            kms[nm] = {"launches": n, "ms": round(ms, 1)}
+    h = hist[0]
+    sirt_ms = sum(v["ms"] for k, v in kms.items() if k != "k_cost_grad" and k not in ("k_pad", "k_box"))
+    return {"wall_s": round(wall, 2), "unit": "s", "config": "%d^3 volume, %d projections, +-2 deg / +-5 px pose errors: %d SIRT iterations (positivity) at the "
+            "nominal poses + one lock-step L-BFGS-B alignment pass (tx, tz, alpha, beta from zero, bounds +-6 px / +-0.05 rad)" % (N, n_proj, sirt_iters),
+            "sirt_kernel_s": round(sirt_ms / 1e3, 3), "alignment_kernel_s": round(kms.get("k_cost_grad", {}).get("ms", 0.0) / 1e3, 3),
+            "alignment_evals": int(h["evals"]), "alignment_launches": int(h["launches"]),
+            "evals_per_sec_end_to_end": round(h["evals"] / max(1e-9, h.get("align_wall_s", wall)), 1),
+            "sirt_wall_s": h.get("sirt_wall_s"), "align_wall_s": h.get("align_wall_s"),
+            "shift_err_px": {"before": float(np.abs(xyz[:, [0, 2]]).mean()), "after": h["shift_err_px"]},
+            "tilt_err_deg": {"before": float(np.rad2deg(np.abs(np.column_stack([alpha, beta])).mean())), "after": h["tilt_err_deg"]},
+            "rmse_after_sirt": h["rmse"], "residual_after_alignment": h["residual"], "kernels": kms}
+
+
 def _cpu_share():
     """Cores this process may actually use: the cgroup CPU quota if there is one, else the affinity mask."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -485,17 +568,24 @@ def _cpu_share():
 
 
 def cpu_baseline(be, d_true, N, n_proj, phi):
-    """Time the CPU oracle (plain-C port of the reference algorithm; 2-3x FASTER than the reference's own Fortran on the same
-    core) on a bounded sample of the same workload, forward + exact adjoint:
-      value      ONE thread, like the reference's serial Fortran: every 8th detector row of 2 angles (an unbiased 1/8 sample
-                 of their rays), extrapolated linearly in rays and angles;
-      all_cores  OpenMP over rays on the box's CPU share: 16 whole angles, extrapolated linearly in angles."""
+    """Host-CPU baselines on this box, each on a bounded sample of the same workloads:
+      value / all_cores   the CPU oracle (oracle/: plain-C port of the reference algorithm, 2-3x FASTER than the reference's own
+                          Fortran on the same core), forward + exact adjoint of the N^3 workload:
+                          ONE thread on every 8th detector row of 2 angles; OpenMP over rays on the box's CPU share on 16 whole
+                          angles (everything in full when N <= 256: configs 1 and 2) -- SIRT iterations/s, extrapolated linearly;
+      gradient            the oracle's projection + 6-DoF gradient (src/ray_wt_grad.f90:95-223 restated) of config-5 poses:
+                          evals/s on one thread (1/8 of a pose's rays) and on all cores (two whole poses);
+      reference           the REFERENCE ITSELF: its untouched Fortran (forward_project_, compute_gradient_) built by
+                          oracle/build_ref.sh into oracle/_ref/libref_mf.so, timed by tools/ref_baseline.py in a child process
+                          (kind "reference"); its SIRT back-projection is a scipy product of a matrix that cannot exist at this
+                          size, so the exact adjoint stays a port figure."""
     from oracle import oracle as orc
     x = be.download(d_true)
     n_cpu = _cpu_share()
+    full = N <= 256
     orc.set_threads(1)
     og1 = orc.Geo(1, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
-    rows = np.arange(3, N, 8)
+    rows = np.arange(N) if full and N <= 128 else np.arange(3, N, 8)
     ray_idx = (rows[:, None] * N + np.arange(N)[None, :]).ravel()
     frac = ray_idx.size / float(N * N)
     picks = [n_proj // 3, (2 * n_proj) // 3 + 1]             # generic (non axis-aligned) angles
@@ -509,15 +599,16 @@ def cpu_baseline(be, d_true, N, n_proj, phi):
         tf += (t1 - t0) / frac / len(picks)
         ta += (t2 - t1) / frac / len(picks)
     out = {"value": round(1.0 / ((tf + ta) * n_proj), 8), "unit": "it/s", "cores": 1, "kind": "port",
-           "sample": "every 8th detector row of %d of %d angles of the same %d^3 workload on one host core (forward %.1f s + exact adjoint %.1f s per "
-                     "whole angle), extrapolated linearly in rays and angles" % (len(picks), n_proj, N, tf, ta),
+           "sample": "%s detector rows of %d of %d angles of the same %d^3 workload on one host core (forward %.2f s + exact adjoint %.2f s per "
+                     "whole angle), extrapolated linearly in rays and angles" % ("all" if rows.size == N else "every 8th of the", len(picks), n_proj, N, tf, ta),
+           "forward_s": round(tf * n_proj, 3), "backproj_s": round(ta * n_proj, 3),
            "host_cpus": os.cpu_count(), "cpu_share": n_cpu,
-           "calibration": "the oracle runs 2-3x faster than the reference's own flang-built Fortran on one core (BASELINE.md section 4)"}
+           "calibration": "the oracle runs 2-3x faster than the reference's own flang-built Fortran on one core (BASELINE.md section 4; `reference` below, same run)"}
     if n_cpu > 1:
-        n_ang = 16 if n_cpu >= 8 else 2
+        n_ang = n_proj if full else (16 if n_cpu >= 8 else 2)
         orc.set_threads(n_cpu)
         og = orc.Geo(n_ang, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
-        ph = phi[n_proj // 3: n_proj // 3 + n_ang]
+        ph = phi if full else phi[n_proj // 3: n_proj // 3 + n_ang]
         t0 = time.perf_counter()
         ax = orc.forward(og, x, phi=ph)
         t1 = time.perf_counter()
@@ -525,10 +616,72 @@ def cpu_baseline(be, d_true, N, n_proj, phi):
         t2 = time.perf_counter()
         fa, aa = (t1 - t0) / n_ang, (t2 - t1) / n_ang
         out["all_cores"] = {"value": round(1.0 / ((fa + aa) * n_proj), 8), "unit": "it/s", "cores": n_cpu,
-                            "sample": "%d of %d whole angles (forward %.2f s + adjoint %.2f s per angle on %d threads, OpenMP over rays)"
-                                      % (n_ang, n_proj, fa, aa, n_cpu)}
+                            "forward_s": round(fa * n_proj, 3), "backproj_s": round(aa * n_proj, 3),
+                            "sample": "%s (forward %.3f s + adjoint %.3f s per angle on %d threads, OpenMP over rays)"
+                                      % ("all %d angles, in full" % n_proj if full else "%d of %d whole angles" % (n_ang, n_proj), fa, aa, n_cpu)}
+    # ---- alignment gradient (config 5; the size align_rate() uses for this N)
+    Ng = min(512, max(32, N // 2))
+    rng = np.random.default_rng(5)
+    n5 = 720
+    phi5 = np.linspace(0., np.pi, n5)
+    alpha5, beta5 = np.deg2rad(rng.uniform(-2, 2, n5)), np.deg2rad(rng.uniform(-2, 2, n5))
+    tx5, tz5 = rng.uniform(-5, 5, n5), rng.uniform(-5, 5, n5)
+    from tomography_alignment_amd.utilities.generate_phantom import SHEPP_LOGAN
+    xg32 = be.download(be.phantom(be.empty(Ng ** 3), (Ng, Ng, Ng), SHEPP_LOGAN))
+    xg = np.ascontiguousarray(xg32, np.float64)
+    ogg = orc.Geo(1, np.array([Ng, Ng, Ng]), np.ones(3), np.array([Ng, Ng]), np.ones(2))
+    pose = lambda i: (alpha5[i], beta5[i], phi5[i], np.array([tx5[i], 0.0, tz5[i]]), np.zeros(3))      # noqa: E731
     orc.set_threads(1)
+    rows = np.arange(3, Ng, 8)
+    idx = (rows[:, None] * Ng + np.arange(Ng)[None, :]).ravel()
+    t0 = time.perf_counter()
+    orc.projection_gradient_rays(ogg, xg, *pose(240), idx)
+    tg1 = (time.perf_counter() - t0) * (Ng * Ng) / idx.size
+    grad = {"evals_per_sec": round(1.0 / tg1, 5), "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": "every 8th detector row of one of the 720 config-5 poses (%d^3, +-2 deg / +-5 px) on one host core: %.2f s per whole evaluation, "
+                      "extrapolated linearly in rays" % (Ng, tg1)}
+    if n_cpu > 1:
+        orc.set_threads(n_cpu)
+        all_idx = np.arange(Ng * Ng)
+        t0 = time.perf_counter()
+        for i in (240, 481):
+            orc.projection_gradient_rays(ogg, xg, *pose(i), all_idx)
+        tga = (time.perf_counter() - t0) / 2
+        grad["all_cores"] = {"evals_per_sec": round(1.0 / tga, 4), "cores": n_cpu, "sample": "two whole config-5 poses on %d threads (OpenMP over rays): %.2f s per evaluation" % (n_cpu, tga)}
+    orc.set_threads(1)
+    out["gradient"] = grad
+    del xg
+    # ---- the reference itself (a compiled binary of its untouched Fortran), in a child process
+    out["reference"] = reference_baseline(x, N, n_proj, xg32, Ng)
     return out
+
+
+def reference_baseline(x, N, n_proj, xg32, Ng):
+    """cpu_baseline.reference: tools/ref_baseline.py on volumes handed over through /dev/shm (or the temp dir)."""
+    import tempfile
+    lib = os.path.join(ROOT, "oracle", "_ref", "libref_mf.so")
+    if not os.path.exists(lib):
+        return {"kind": "reference", "available": False, "reason": "oracle/_ref/libref_mf.so is not in this tree (built by oracle/build_ref.sh where /root/reference exists)"}
+    d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    f1, f2 = os.path.join(d, "tomo_bench_%d_fwd.npy" % os.getpid()), os.path.join(d, "tomo_bench_%d_grad.npy" % os.getpid())
+    try:
+        np.save(f1, np.ascontiguousarray(x, np.float32).ravel())
+        np.save(f2, np.ascontiguousarray(xg32, np.float32).ravel())
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ref_baseline.py"), lib, f1, str(N), str(n_proj), f2, str(Ng)],
+                           capture_output=True, text=True, timeout=600)
+        if r.returncode != 0 or not r.stdout.strip():
+            return {"kind": "reference", "available": False, "reason": "tools/ref_baseline.py exited with %s: %s" % (r.returncode, (r.stderr or "").strip()[-300:])}
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        j["available"] = True
+        return j
+    except (OSError, ValueError, subprocess.TimeoutExpired) as e:
+        return {"kind": "reference", "available": False, "reason": repr(e)[:300]}
+    finally:
+        for f in (f1, f2):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
 
 
 def copy_probe(ctx, be, n_bytes=1 << 31):

@@ -303,6 +303,23 @@ def projection_gradient(geo, rec, alpha, beta, phi, xyz_shift, cor_shift3, preci
     return img.astype(precision, copy=False), grad.astype(precision, copy=False)
 
 
+def projection_gradient_rays(geo, rec64, alpha, beta, phi, xyz_shift, cor_shift3, ray_index):
+    """projection_gradient restricted to the rays `ray_index` (same loop; bench.py times a fraction of a pose's rays with it).
+    `rec64` must already be a contiguous float64 array (no per-call conversion of a large volume)."""
+    p0, rhat, n, r_len0, src, det = ray_setup(geo, alpha, beta, phi, xyz_shift, cor_shift3)
+    idx = np.asarray(ray_index, np.int64)
+    ray_vec = (det - src)[:, 0]
+    der = np.ascontiguousarray(derivative_ray_points(src[:, idx], ray_vec, alpha, beta, phi, xyz_shift))
+    nx, ny, nz = (int(v) for v in geo.vox_shape)
+    assert rec64.dtype == np.float64 and rec64.flags["C_CONTIGUOUS"]
+    img = np.zeros(idx.size, np.float64)
+    grad = np.zeros((6, idx.size), np.float64)
+    _lib().orc_trilinear_ray_interp(_p(np.ascontiguousarray(p0[:, idx])), _p(np.ascontiguousarray(rhat[:, idx])), ctypes.c_int64(idx.size), n,
+                                    ctypes.c_double(geo.step_size), ctypes.c_double(r_len0),
+                                    nx, ny, nz, _p(rec64.ravel()), _p(der), _p(img), _p(grad))
+    return img, grad
+
+
 def ray_face_distance(geo, alpha, beta, phi, xyz_shift, cor_shift3):
     """Test aid: per ray, the smallest distance (voxels) of an in-volume sample to a cell face (orc_ray_face_distance).
     The pose gradient of a ray with a sample within position rounding of a face is ill-conditioned (the interpolant's

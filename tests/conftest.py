@@ -34,3 +34,24 @@ def rel_l2(a, b):
 @pytest.fixture(scope="session")
 def shepp32():
     return golden("g7_phantom")["shepp32"]
+
+
+def g10_case():
+    """Golden G10 (tests/golden/make_golden.py::g10): the volume is regenerated from its seed and checked against the stored
+    checksum; returns (g, x float64 [N,N,N], grad32 in the Python API's row order tx, ty, tz, phi, alpha, beta)."""
+    import hashlib
+    g = golden("g10_face_gradient")
+    N = int(g["N"])
+    x = np.random.default_rng(int(g["seed"])).uniform(0.0, 1.0, (N, N, N)).astype(np.float32).astype(np.float64)
+    sha = np.frombuffer(hashlib.sha256(x.astype(np.float32).tobytes()).digest(), np.uint8)
+    if not np.array_equal(sha, g["vol_sha256"]):
+        pytest.skip("this numpy's default_rng stream differs from the one that generated G10's volume")
+    g32 = g["grad32_fortran_rows"][:, [0, 1, 2, 5, 3, 4], :]      # src/external_forward_projection.f90:64-69 orders tx, ty, tz, alpha, beta, phi
+    return g, x, g32
+
+
+def grad_dev_per_ray(g, g0):
+    """Per ray, max over the 6 rows of |g - g0| / (largest row maximum of the same unit: translations, angles)."""
+    g, g0 = np.asarray(g, np.float64), np.asarray(g0, np.float64)
+    unit = [max(np.max(np.abs(g0[r])) for r in grp) for grp in ((0, 1, 2), (3, 4, 5)) for _ in grp]
+    return np.max([np.abs(g[r] - g0[r]) / unit[r] for r in range(6)], axis=0)

@@ -332,7 +332,57 @@ def g9():
     save("g9_regularized", **out)
 
 
+# ------------------------------------------------------------------ G10 the pose gradient at cell faces: the reference's f32 twin vs its f64 path
+def g10_volume(N=64, seed=77):
+    """A volume on which EVERY cell face carries an O(1) jump of the interpolant's gradient (independent uniform voxels, rounded to
+    float32 so that the float64 and the float32 routines see the same values).  The fixture stores the seed and a checksum."""
+    return np.random.default_rng(seed).uniform(0.0, 1.0, (N, N, N)).astype(np.float32).astype(np.float64)
+
+
+def g10():
+    """Per ray, for two +-2 deg / +-5 px poses at 64^3: the float64 `projection_gradient` (utilities/projection_operators.py:112-122
+    -> src/ray_wt_grad.f90:95-223) and the float32 `compute_gradient_` (src/projection_gradient.f90:1-79) of the SAME poses.  Where
+    a sample of a ray lies within float32 position rounding of a cell face the two disagree by O(1e-2) -- the reference's own
+    float32 implementation puts that sample on the other side of the face, where the interpolant's gradient differs -- and they
+    agree to ~7e-6 everywhere else: the behaviour tests/test_gpu_configs.py exempts with its face-distance mask."""
+    import hashlib
+    import resource
+    resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))   # compute_gradient_'s automatic arrays
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_mf.so"))
+    N, seed = 64, 77
+    x = g10_volume(N, seed)
+    rng = np.random.default_rng(10)
+    phi = np.array([0.83, 2.31])
+    alpha, beta = np.deg2rad(rng.uniform(-2, 2, 2)), np.deg2rad(rng.uniform(-2, 2, 2))
+    xyz = np.zeros((2, 3))
+    xyz[:, 0], xyz[:, 2] = rng.uniform(-5, 5, 2), rng.uniform(-5, 5, 2)
+    geo = geom(1, N)
+    P64 = projection_operators.ProjectionMatrix(geo, precision=np.float64)
+    f32 = np.float32
+    F = lambda a: np.asfortranarray(a, dtype=f32)  # noqa: E731
+    I = lambda v: ctypes.byref(ctypes.c_int32(int(v)))  # noqa: E731
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    src, det, org = F(geo.source_centers), F(geo.det_centers), F(geo.vox_origin)
+    rec = F(x.ravel())
+    step = ctypes.byref(ctypes.c_float(1.0))
+    p64, g64, p32, g32 = [], [], [], []
+    for i in range(2):
+        p, g = P64.projection_gradient(x, alpha[i], beta[i], phi[i], xyz[i], np.zeros(3))
+        p64.append(p)
+        g64.append(g)
+        a1 = np.zeros(geo.n_det, dtype=f32)
+        d1 = np.zeros((6, geo.n_det), dtype=f32, order="F")
+        lib.compute_gradient_(ctypes.byref(ctypes.c_float(alpha[i])), ctypes.byref(ctypes.c_float(beta[i])),
+                              ctypes.byref(ctypes.c_float(phi[i])), P(F(xyz[i])), P(F(np.zeros(3))), P(src), P(det), P(org), step,
+                              I(N), I(N), I(N), P(rec), I(geo.n_det), I(geo.n_vox), P(a1), P(d1))
+        p32.append(a1.copy())
+        g32.append(np.array(d1))                 # rows as the Fortran orders them: tx, ty, tz, alpha, beta, phi
+    save("g10_face_gradient", N=np.array(N), seed=np.array(seed), vol_sum=np.array(x.sum()),
+         vol_sha256=np.frombuffer(hashlib.sha256(x.astype(np.float32).tobytes()).digest(), np.uint8),
+         phi=phi, alpha=alpha, beta=beta, xyz=xyz, proj64=np.array(p64), grad64=np.array(g64), proj32=np.array(p32), grad32_fortran_rows=np.array(g32))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g7", "g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9"]
+    which = sys.argv[1:] or ["g7", "g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()

@@ -193,21 +193,21 @@ def test_alignment_cost_gradient_pairs_vs_reference_golden(shepp32):
     af = alignment_functions
     for tag in ("zero", "gen"):
         p = g["p_" + tag]
-        assert np.isclose(af.cost_xzab(p, *args), g["cost_xzab_" + tag], rtol=1e-4, atol=1e-9)
-        assert rel_max(af.gradient_xzab(p, *args), g["grad_xzab_" + tag]) < 1e-4
+        assert np.isclose(af.cost_xzab(p, *args), g["cost_xzab_" + tag], rtol=1e-5, atol=1e-9)
+        assert rel_max(af.gradient_xzab(p, *args), g["grad_xzab_" + tag]) < 1e-5
         p5 = np.array([p[0], p[1], 0.003, p[2], p[3]])
-        assert np.isclose(af.cost_xzpab(p5, *args), g["cost_xzpab_" + tag], rtol=1e-4, atol=1e-9)
-        assert rel_max(af.gradient_xzpab(p5, *args), g["grad_xzpab_" + tag]) < 1e-4
+        assert np.isclose(af.cost_xzpab(p5, *args), g["cost_xzpab_" + tag], rtol=1e-5, atol=1e-9)
+        assert rel_max(af.gradient_xzpab(p5, *args), g["grad_xzpab_" + tag]) < 1e-5
     pg = g["p_gen"]
     sc = np.array([1.0, 2.0, 50.0, 25.0])
-    assert rel_max(af.gradient_xzab(pg, *args, scale_factor=sc), g["grad_xzab_scaled"]) < 1e-4
+    assert rel_max(af.gradient_xzab(pg, *args, scale_factor=sc), g["grad_xzab_scaled"]) < 1e-5
     assert rel_max(af.gradient_xzab(pg, *args, return_vector=True), g["grad_xzab_vec"]) < 1e-5
     assert rel_max(af.cost_xzab(pg, *args, return_vector=True), g["cost_xzab_vec"]) < 1e-5
     for nm, p in (("xz", [0.4, -0.7]), ("x", [0.4]), ("z", [-0.7]), ("ab", [0.004, -0.006]), ("a", [0.004]), ("b", [-0.006]),
                   ("xzb", [0.4, -0.7, -0.006])):
         p = np.array(p)
-        assert np.isclose(getattr(af, "cost_" + nm)(p, *args), g["cost_" + nm], rtol=1e-4), nm
-        assert rel_max(getattr(af, "gradient_" + nm)(p, *args), g["grad_" + nm]) < 1e-4, nm
+        assert np.isclose(getattr(af, "cost_" + nm)(p, *args), g["cost_" + nm], rtol=1e-5), nm
+        assert rel_max(getattr(af, "gradient_" + nm)(p, *args), g["grad_" + nm]) < 1e-5, nm
     # the reference's finite-difference checkers agree with the analytic gradient to FD accuracy
     fd = af.gradient_xz_fd(np.array([0.4, -0.7]), *args)
     assert rel_max(fd, g["grad_xz"]) < 5e-2
@@ -372,12 +372,17 @@ def test_bench_launcher_and_roofline_logic_without_a_gpu(tmp_path, monkeypatch):
     import bench
     prof = tmp_path / "profiles"
     prof.mkdir()
-    json.dump({"key": "K", "source": "t", "kernels": {"k_fwd_tile_flat": {"SQ_INSTS_VALU": 2.0e11, "SQ_INSTS_LDS": 6.0e10, "lds_bytes": 6.0e10 * 512,
-                                                                          "SQ_ACTIVE_INST_VALU": 1.5e11, "SQ_LDS_IDX_ACTIVE": 2.4e11}}},
-              open(prof / "sq_counters.json", "w"))
-    json.dump({"key": "K", "source": "t", "kernels": {"k_fwd_tile_flat": {"hbm_bytes_per_launch": 4.0e11}}}, open(prof / "pmc_traffic.json", "w"))
+    live = _lib.kernel_source_hash()
+    sqj = {"key": "K", "source": "t", "src_hash": live, "kernels": {"k_fwd_tile_flat": {"SQ_INSTS_VALU": 2.0e11, "SQ_INSTS_LDS": 6.0e10, "lds_bytes": 6.0e10 * 512,
+                                                                                        "SQ_ACTIVE_INST_VALU": 1.5e11, "SQ_LDS_IDX_ACTIVE": 2.4e11}}}
+    trj = {"key": "K", "source": "t", "src_hash": live, "kernels": {"k_fwd_tile_flat": {"hbm_bytes_per_launch": 4.0e11, "write_kb": 2.6e11 / 1024.0}}}
+    json.dump(sqj, open(prof / "sq_counters.json", "w"))
+    json.dump(trj, open(prof / "pmc_traffic.json", "w"))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    r = bench.make_roofline("k_fwd_tile_flat", 500.0, 1.0, 4.4e12, "K")
+    r = bench.make_roofline("k_fwd_tile_flat", 500.0, 1.0, 4.4e12, "K", 1024.0 * 1024.0 ** 3, 4.0 * 1024 * 1024 ** 2)
+    # useful work: 1024 angles x 1024^3 samples x 8 flop / 0.5 s = 17.6 TF of 157.3; atomics: 2.6e11 B / 0.5 s = 520 GB/s of 1300
+    assert abs(r["useful_flop_frac"] - 8 * 1024.0 ** 4 / 0.5 / 1e12 / 157.3) < 1e-3 and abs(r["atomics_frac"] - 0.4) < 1e-3
+    assert abs(r["atomics"]["amplification_vs_sinogram"] - 2.6e11 / (4.0 * 1024 ** 3)) < 0.1
     # LDS-array cycles 2.4e11 / 0.5 s = 480 G/s of the 614.4 G/s (256 CUs x 2.4 GHz) = 0.78; VALU 4 x 1.5e11 / 0.5 = 1200 of 2457.6 = 0.49
     assert r["bound"] == "lds" and 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - 2.4e11 / 0.5 / 1e9 / 614.4) < 1e-3
     assert abs(r["utilisation"]["valu"]["frac"] - 4 * 1.5e11 / 0.5 / 1e9 / 2457.6) < 1e-3 and r["utilisation"]["hbm"]["frac"] < 0.2
@@ -385,6 +390,14 @@ def test_bench_launcher_and_roofline_logic_without_a_gpu(tmp_path, monkeypatch):
     assert r["instruction_rates"]["lds_GBps"] > 0
     r2 = bench.make_roofline("k_fwd_tile_flat", 500.0, 1.0, 4.4e12, "other-workload")
     assert r2["bound"] == "hbm" and r2["counters"] is None and "no committed PMC counters" in r2["note"]
+    # counters taken on OTHER kernel sources are refused, and the line says so
+    sqj["src_hash"] = trj["src_hash"] = "0123456789abcdef"
+    json.dump(sqj, open(prof / "sq_counters.json", "w"))
+    json.dump(trj, open(prof / "pmc_traffic.json", "w"))
+    r3 = bench.make_roofline("k_fwd_tile_flat", 500.0, 1.0, 4.4e12, "K", 1024.0 * 1024.0 ** 3, 4.0 * 1024 * 1024 ** 2)
+    assert r3["counters"] is None and r3["traffic"] is None and r3["bound"] == "hbm" and len(r3["stale_counters_refused"]) == 2
+    assert "atomics_frac" not in r3 and r3["useful_flop_frac"] > 0            # the live-time figure needs no counters
+    assert len(live) == 16 and live == _lib.kernel_source_hash()
 
 
 def test_samples_per_ray_match_numpy_rounding():

@@ -298,6 +298,21 @@ class DeviceArray(object):
             pass
 
 
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the HIP sources libtomo_hip.so is built from (csrc/*.hip, *.hip.h, *.h, Makefile), in name
+    order.  The committed PMC counters (profiles/sq_counters.json, profiles/pmc_traffic.json) carry the hash of the sources they were
+    taken on; bench.py refuses them when the kernels have changed since (counts of an old kernel must never be
+    divided by the time of a new one)."""
+    import glob
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def geom_struct(geometry):
     """Fill struct tomo_geom from a Geometry-like object (utilities/geometry.py:14-47,77-105)."""
     g = TomoGeom()

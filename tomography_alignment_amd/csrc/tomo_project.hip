@@ -15,10 +15,10 @@
 //   k_proj_grad<FUSED>                 src/ray_wt_grad.f90:95-223 ; src/projection_gradient.f90:1-79 ;
 //                                      utilities/alignment_functions.py:16-37,124,146 (FUSED)
 //
-// The kernels live in three included files (one translation unit): kernels_ray.hip.h (k_pad/k_unpad, k_fwd_v1/v2, k_adj_v1,
-// k_bp_voxel), kernels_tile.hip.h (k_tile, k_tile_flat, k_fwd_flat_z, k_adj_gather_flat, k_absmax), kernels_grad.hip.h
-// (k_proj_grad, k_proj_grad_v2, k_proj_grad_v3); this file holds the host side of the C-ABI and the small-N kernels
-// (k_triplets, k_vox_splat).
+// The kernels live in five included files (one translation unit): kernels_ray.hip.h (k_pad/k_unpad, k_fwd_v1/v2, k_adj_v1,
+// k_bp_voxel), kernels_tile.hip.h (tile shape, AdjC, helpers, k_absmax, the general k_tile), kernels_tile_flat.hip.h (k_tile_flat,
+// k_fwd_flat_z), kernels_tile_gather.hip.h (k_adj_gather_flat), kernels_grad.hip.h (k_proj_grad, k_proj_grad_v2, k_proj_grad_v3);
+// this file holds the host side of the C-ABI and the small-N kernels (k_triplets, k_vox_splat).
 #include <limits.h>
 #include <string.h>
 
@@ -29,6 +29,8 @@
 
 #include "kernels_ray.hip.h"
 #include "kernels_tile.hip.h"
+#include "kernels_tile_flat.hip.h"
+#include "kernels_tile_gather.hip.h"
 #include "kernels_grad.hip.h"
 
 // ------------------------------------------------------------------------------------------------

@@ -8,6 +8,7 @@ projections in lock step, one fused cost/gradient launch per round (tomography_a
     python -m tomography_alignment_amd.examples.align_rigid data.npz --outer 5 --sirt-iters 50
 """
 import argparse
+import time
 
 import numpy as np
 
@@ -33,12 +34,16 @@ def run(data, n_outer=5, sirt_iters=50, bounds=((-3., 3.), (-3., 3.), (-0.02, 0.
             opts["ground_truth"] = ground_truth
         if rec is not None:
             opts["rec"] = rec.ravel()                                   # warm start, examples/align_rigid.py:42
+        t0 = time.perf_counter()
         solver = sirt.SIRT(geom, proj.reshape(n_proj, -1), np.array([phi, alpha_rec, beta_rec]).T, xyz_rec, options=opts)
         rec, err = solver.run_main_iteration(niter=sirt_iters, positivity=True)
+        t1 = time.perf_counter()
         res = alignment.align_projections(solver.be, solver.d_rec, proj.reshape(n_proj, -1), phi, letters="xzab", bounds=bounds)
+        t2 = time.perf_counter()
         xyz_rec[:, 0], xyz_rec[:, 2] = res["x"][:, 0], res["x"][:, 1]
         alpha_rec, beta_rec = res["x"][:, 2].copy(), res["x"][:, 3].copy()
-        entry = {"outer": it, "rmse": float(err[-1]), "residual": float(res["fun"].sum()), "launches": res["n_launch"], "evals": res["n_eval"]}
+        entry = {"outer": it, "rmse": float(err[-1]), "residual": float(res["fun"].sum()), "launches": res["n_launch"], "evals": res["n_eval"],
+                 "sirt_wall_s": round(t1 - t0, 3), "align_wall_s": round(t2 - t1, 3)}
         if "xyz" in data:
             entry["shift_err_px"] = float(np.abs(xyz_rec[:, [0, 2]] - np.asarray(data["xyz"])[:, [0, 2]]).mean())
             entry["tilt_err_deg"] = float(np.rad2deg(np.abs(np.column_stack([alpha_rec, beta_rec]) -

@@ -12,6 +12,15 @@ import json
 import os
 
 
+def _src_hash():
+    """Hash of the kernel sources the counters were taken on (tomography_alignment_amd._lib.kernel_source_hash): bench.py refuses
+    counters whose hash differs from the sources it runs."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tomography_alignment_amd import _lib
+    return _lib.kernel_source_hash()
+
+
 ALIAS = {"k_adj_gather_flat<3>": "k_adj_gather_flat", "k_adj_gather_flat<6>": "k_adj_gather_flat", "k_tile_flat<true>": "k_fwd_tile_flat", "k_fwd_flat_z<2>": "k_fwd_tile_flat", "k_fwd_flat_z<1>": "k_fwd_tile_flat", "k_tile_flat<false>": "k_adj_tile_flat", "k_tile<true>": "k_fwd_tile",
          "k_tile<false>": "k_adj_tile", "k_proj_grad<true>": "k_cost_grad(v1)", "k_proj_grad<false>": "k_proj_grad(v1)",
          "k_proj_grad_v2<true>": "k_cost_grad(v2)", "k_proj_grad_v2<false>": "k_proj_grad(v2)",
@@ -91,7 +100,7 @@ def main():
             lines.append("| `%s` | %.4g | %.4g | %.4g |" % (k, f, w, b))
     open(os.path.join(a.out, a.tag + "_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
     if traffic:
-        json.dump({"workload": a.workload, "key": a.key, "source": a.tag, "kernels": traffic}, open(os.path.join(a.out, "pmc_traffic.json"), "w"), indent=1)
+        json.dump({"workload": a.workload, "key": a.key, "source": a.tag, "src_hash": _src_hash(), "kernels": traffic}, open(os.path.join(a.out, "pmc_traffic.json"), "w"), indent=1)
     print("\n".join(lines))
 
 
