@@ -1,4 +1,6 @@
-"""Randomised cross-check on the GPU: the LDS tile kernels (flat and general, forward and adjoint) against the ray-driven /
+"""(Self-comparison notice: in test_gradient_kernels_agree_on_random_geometry the fused 6-vector is compared with the kernel's OWN
+per-ray outputs; only the cost and the per-ray values go against the oracle there.)
+Randomised cross-check on the GPU: the LDS tile kernels (flat and general, forward and adjoint) against the ray-driven /
 global-atomic kernels (themselves pinned to the oracle and the reference goldens) over odd shapes, steps, detector sizes and
 poses -- including exactly degenerate ones.  A lost or double-counted sample at a tile boundary shows up as a ~1e-3 error."""
 import numpy as np
@@ -172,3 +174,52 @@ def test_gradient_kernels_agree_on_random_geometry(seed):
                 worst_ray = max(worst_ray, ep, eg)
                 assert ep < 2e-6 and eg < 5e-6, ("per ray", v, k, i, shape, ndet, step, np.rad2deg(tilt))    # float32 lerps in another order (2: y, x, z; 3: z, y, x)
     print("worst: per ray between kernels %.2e, per ray vs oracle (well-conditioned rays) %.2e, fused sums vs own rays %.2e" % (worst_ray, worst_orc, worst_sum))
+
+
+def test_samples_per_ray_regression_54x18x27():
+    """Named regression (VERDICT r2 #4 / DESIGN.md section 2): n = int(|r0| / step) (utilities/ray_voxel_utilities.py:88).  On a volume
+    longer in x than in y the last sample of an oblique ray lies INSIDE the object, so n = K - 1 against K changes projections by a
+    whole sample.  Round 2's random-geometry test found this very case: 54 x 18 x 27, detector 34 x 90, and a pose for which numpy
+    rounds |r0| to 35.99999999999999 (n = 35) where plain a*b + c*d + e*f products give 36.0.  Every forward kernel, the adjoint
+    and the gradient's projection must use the reference's n: compared with the oracle (whose set-up IS numpy's), with a second pose
+    of the same set for which n = 36.  (Poses given as hex floats: the case hangs on their last bits.)"""
+    from oracle import oracle as orc
+    from tomography_alignment_amd.utilities.geometry import Geometry
+    from tomography_alignment_amd.utilities.projection_operators import ProjectionMatrix
+    shape, ndet = (54, 18, 27), (34, 90)
+    H = float.fromhex
+    poses = [dict(phi=H('0x1.cfc299c794cc2p-2'), alpha=H('0x1.bab5d57170f6cp-5'), beta=H('-0x1.7b4c94dff3c70p-4'),
+                  xyz=[H('-0x1.306966b584948p-1'), H('0x1.14963379915a4p+1'), H('0x1.fc495499bc910p+1')], cor=H('0x1.d3f6131e24c54p-2'), n=35),
+             dict(phi=H('0x1.9ba1a1c011fe0p+0'), alpha=H('-0x1.af83e7509f454p-5'), beta=H('-0x1.a483605ff7570p-7'),
+                  xyz=[H('0x1.f64eaf3b139b0p+1'), H('-0x1.dd30623693460p-3'), H('0x1.49792d38fcb22p+1')], cor=H('0x1.52dad6ec8496ep-1'), n=36)]
+    x = np.random.default_rng(2).uniform(0.5, 1.0, shape).astype(np.float32)
+    y = np.random.default_rng(3).standard_normal(ndet[0] * ndet[1]).astype(np.float32)
+    for q in poses:
+        cor3 = np.array([[q["cor"], 0.0, 0.0]])
+        og = orc.Geo(1, np.array(shape), np.ones(3), np.array(ndet), np.ones(2), cor_shift=cor3)
+        assert orc.ray_setup(og, q["alpha"], q["beta"], q["phi"], np.array(q["xyz"]), cor3[0])[2] == q["n"]
+        kw = dict(alpha=np.array([q["alpha"]]), beta=np.array([q["beta"]]), phi=np.array([q["phi"]]), xyz_shift=np.array([q["xyz"]]))
+        want_f = orc.forward(og, x, **kw).ravel()
+        want_a = orc.adjoint(og, y, **kw)
+        geo = Geometry(1, np.array(shape), np.ones(3), np.array(ndet), np.ones(2), cor_shift=cor3)
+        P = ProjectionMatrix(geo)
+        ctx = P.backend.ctx
+        A = P.projection_matrix(**kw)
+        for fv, av in ((3, 2), (2, 2), (1, 1)):
+            ctx.set_option("fwd_variant", fv)
+            ctx.set_option("adj_variant", av)
+            assert rel_max(A.dot(x.ravel()), want_f) < 1e-5, (q["n"], "forward variant", fv)
+            assert rel_max(A.T.dot(y), want_a) < 1e-5, (q["n"], "adjoint variant", av)
+        ctx.set_option("fwd_variant", 3)
+        ctx.set_option("adj_variant", 2)
+        for gv in (1, 2, 3, 4):
+            ctx.set_option("grad_variant", gv)
+            p, _ = P.projection_gradient(x, q["alpha"], q["beta"], q["phi"], np.array(q["xyz"]), cor3[0])
+            assert rel_max(p, want_f) < 1e-5, (q["n"], "gradient variant", gv)
+        ctx.set_option("grad_variant", 4)
+        if q["n"] == 35:
+            # the sensitivity that makes this a regression: with one sample more (step nudged so that int() gives 36) the rays that end
+            # inside the object change by a whole sample
+            og36 = orc.Geo(1, np.array(shape), np.ones(3), np.array(ndet), np.ones(2), cor_shift=cor3, step_size=1.0 - 1e-12)
+            assert orc.ray_setup(og36, q["alpha"], q["beta"], q["phi"], np.array(q["xyz"]), cor3[0])[2] == 36
+            assert rel_max(orc.forward(og36, x, **kw).ravel(), want_f) > 1e-3
