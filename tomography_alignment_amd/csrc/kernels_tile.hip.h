@@ -59,6 +59,13 @@ __device__ __forceinline__ int cvt_round_i32(float x)
 // packed ops directly: p00 = (v000, v001), p01 = (v010, v011), p10 = (v100, v101), p11 = (v110, v111)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) float lds_cfloat;
+// ... the same up to the z lerp: (value at z, value at z + 1)
+__device__ __forceinline__ f32x2 bilerp_pairs(f32x2 p00, f32x2 p01, f32x2 p10, f32x2 p11, float wx, float wy)
+{
+    const f32x2 c0 = p00 + wy * (p01 - p00);
+    const f32x2 c1 = p10 + wy * (p11 - p10);
+    return c0 + wx * (c1 - c0);
+}
 __device__ __forceinline__ float trilerp_pairs(f32x2 p00, f32x2 p01, f32x2 p10, f32x2 p11, float wx, float wy, float wz)
 {
     const f32x2 c0 = p00 + wy * (p01 - p00);
@@ -81,6 +88,28 @@ __device__ __forceinline__ unsigned select_lanes_u(unsigned v, unsigned long lon
     unsigned r;
     asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
     return r;
+}
+
+// acc + v in the lanes whose bit is set in the wave-uniform mask m, acc unchanged in the others: the add runs under EXEC & m (three
+// scalar instructions, no branch) instead of a v_cndmask + v_add pair -- one VALU instruction less per sample in a VALU-bound loop
+__device__ __forceinline__ float add_lanes(float acc, float v, unsigned long long m)
+{
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %3\n\tv_add_f32 %0, %0, %2\n\ts_mov_b64 exec, %1"
+                 : "+v"(acc), "=&s"(saved) : "v"(v), "s"(m) : "scc");      // s_and_b64 writes SCC (round 3: without the clobber the compiler kept a
+                                                                           // loop condition in SCC across this statement -- the loop never ended)
+    return acc;
+}
+
+// The last (z) lerp and the accumulation of a sample, for the lanes of mask m only:  acc += e0 ;  accz += fz * (e1 - e0)  with fz the
+// z fraction as it comes out of v_cvt_f32_u32 (x 2^32): the caller adds accz * 2^-32 once per row chunk instead of scaling every
+// sample's fraction -- with the select gone too (add_lanes) that is 3 VALU instructions where there were 5.
+__device__ __forceinline__ void zlerp_acc_lanes(float &acc, float &accz, float e0, float e1, float fz, unsigned long long m)
+{
+    unsigned long long saved;
+    const float d = e1 - e0;
+    asm volatile("s_mov_b64 %2, exec\n\ts_and_b64 exec, exec, %6\n\tv_add_f32 %0, %0, %3\n\tv_fmac_f32 %1, %4, %5\n\ts_mov_b64 exec, %2"
+                 : "+v"(acc), "+v"(accz), "=&s"(saved) : "v"(e0), "v"(fz), "v"(d), "s"(m) : "scc");   // SCC: see add_lanes
 }
 
 // b where the lane's bit is set in m, else a
@@ -115,6 +144,29 @@ __device__ __forceinline__ int64_t add64_vs(int64_t p, int64_t step)
 // exact and order-independent, so every tile computes the identical cell and fraction for a sample (consistent ownership,
 // A^T uses exactly A's weights) without any float64 work in the kernel; resolution 2^-32 voxel, accumulated rounding of the
 // lattice constants < 1e-6 voxel at 1024^3.
+// dword index of cell (cx, cy, cz) of the LDS image, (cx * ALY + cy) * ALZ + cz, in two full-rate instructions (v_lshl_add_u32,
+// v_mad_u32_u24 -- left to itself the compiler picked the quarter-rate v_mad_u64_u32 once the cells were no longer provably small).
+// Round 3: the cells of a lane that does NOT own the sample are not clamped into the image any more (two v_min_u32 and one v_and
+// per sample).  Whatever (cx, cy) are, cz's low five bits -- the lanes are consecutive detector-z rays -- set the bank, so the 32
+// lanes of a bank group still hit 32 banks; the dword lies either somewhere in the image (read and discarded by the ownership
+// select / added an integer 0) or beyond the work-group's LDS allocation, where DS reads return 0 and DS writes are dropped (LDS
+// accesses are bounds-checked in hardware; they never fault).
+__device__ __forceinline__ unsigned tile_cell_dword(unsigned cx, unsigned cy, unsigned cz)
+{
+    static_assert(ALY * ALZ == 1088 && ALZ == 64, "immediates below");
+    unsigned u, r;
+    asm("v_lshl_add_u32 %0, %1, 6, %2" : "=v"(u) : "v"(cy), "v"(cz));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(cx), "s"((unsigned)(ALY * ALZ)), "v"(u));      // VOP3 takes no 32-bit literal: the pitch sits in an SGPR
+    return r;
+}
+
+#ifdef TOMO_TILE_CLAMP          // A/B switch (tools/gpu_r3c.sh): the round-2 form with the non-owners' cells clamped into the image
+#define TILE_CLAMP(v, hi) min((v), (unsigned)(hi))
+#define TILE_ZMASK(v) ((v) & 63u)
+#else
+#define TILE_CLAMP(v, hi) (v)
+#define TILE_ZMASK(v) (v)
+#endif
 template <bool FWD>
 __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
                                                          float *__restrict__ vol, TomoGeomC g, const unsigned *__restrict__ absmax_bits,
@@ -235,7 +287,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
                         if (FWD) {
                             // branch-free body (lanes that do not own the sample read LDS word 0 and discard it), so the compiler
                             // can overlap the LDS latency of consecutive samples
-                            float part = 0.f;
+                            float part = 0.f, partz = 0.f;
                             for (int jj = 0; jj < cnt; ++jj) {
                                 const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32), lz = (unsigned)(pz >> 32);
                                 static_assert(ATX == ATY && (ATX & (ATX - 1)) == 0, "ownership test uses (lx | ly) < ATX");
@@ -245,18 +297,21 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
                                 // bank is the one their own z would have -- lanes sit on consecutive z, so the 32 lanes of a bank group keep
                                 // 32 different banks.  (They used to read word 0: every such lane then hit bank 0 together with whichever
                                 // owner lane mapped there -- SQ_LDS_BANK_CONFLICT was 47 % of the kernel's LDS cycles, LDS 81 % busy.)
-                                const unsigned cx = min(lx, (unsigned)(ATX - 1)), cy = min(ly, (unsigned)(ATY - 1)), cz = lz & 63u;
-                                const unsigned eb = (((cx << 4) + cx + cy) << 8) + (cz << 2);          // byte offset of cell (cx, cy, cz): (cx * ALY + cy) * ALZ + cz, no quarter-rate multiply
-                                const float wx = (float)(unsigned)px * two_m32, wy = (float)(unsigned)py * two_m32, wz = (float)(unsigned)pz * two_m32;
+                                const unsigned cx = TILE_CLAMP(lx, ATX - 1), cy = TILE_CLAMP(ly, ATY - 1), cz = TILE_ZMASK(lz);      // see tile_cell_dword
+                                const unsigned eb = tile_cell_dword(cx, cy, cz) << 2;                   // byte offset of the cell
+                                const f32x2 wxy = f32x2{(float)(unsigned)px, (float)(unsigned)py} * two_m32;          // one packed multiply for two of the three fractions
+                                const float wx = wxy.x, wy = wxy.y, fz32 = (float)(unsigned)pz;           // z fraction x 2^32 (scaled once per chunk)
                                 unsigned eb1 = eb + ALY * ALZ * 4;
                                 asm("" : "+v"(eb1));                      // one add for the x+1 face; its y+1 rows sit within ds_read2's offset range
                                 const lds_cfloat *q = (const lds_cfloat *)((const __attribute__((address_space(3))) char *)img3 + eb);
                                 const lds_cfloat *q1 = (const lds_cfloat *)((const __attribute__((address_space(3))) char *)img3 + eb1);
                                 const f32x2 p00 = {q[0], q[1]}, p01 = {q[ALZ], q[ALZ + 1]};
                                 const f32x2 p10 = {q1[0], q1[1]}, p11 = {q1[ALZ], q1[ALZ + 1]};
-                                part += select_lanes(trilerp_pairs(p00, p01, p10, p11, wx, wy, wz), own);
+                                const f32x2 e = bilerp_pairs(p00, p01, p10, p11, wx, wy);
+                                zlerp_acc_lanes(part, partz, e.x, e.y, fz32, own);
                                 px = add64_vs(px, c.fd[0]); py = add64_vs(py, c.fd[1]); pz = add64_vs(pz, c.fd[2]);
                             }                                          // (two samples per trip, 8 reads in flight: measured no faster -- the loop is VALU-issue bound)
+                            part = fmaf(partz, two_m32, part);
                             if (lane_ok) atomicAdd(pr, part);          // 64 consecutive floats per wave: the full-rate atomic shape
                         } else {
                             const float ys = (lane_ok ? *pr : 0.f) * scale;
@@ -268,7 +323,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
                             for (int jj = 0; jj < cnt; ++jj) {
                                 const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32), lz = (unsigned)(pz >> 32);
                                 const float yo = select_lanes(ys, __builtin_amdgcn_ballot_w64((lx | ly) < (unsigned)ATX) & __builtin_amdgcn_ballot_w64(lz < (unsigned)ATZ));
-                                const unsigned cx = min(lx, (unsigned)(ATX - 1)), cy = min(ly, (unsigned)(ATY - 1)), cz = lz & 63u;
+                                const unsigned cx = TILE_CLAMP(lx, ATX - 1), cy = TILE_CLAMP(ly, ATY - 1), cz = TILE_ZMASK(lz);      // unclamped: a non-owner adds integer 0 (tile_cell_dword)
                                 // (1 - w, w) per axis as one packed pair, products as packed multiplies: 3 + 7 packed instructions for what
                                 // were 6 + 14 scalar ones (same operations in the same order)
                                 const float fx = (float)(unsigned)px, fy = (float)(unsigned)py, fz = (float)(unsigned)pz;
@@ -276,7 +331,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
                                 const f32x2 a = yo * wxp;
                                 const f32x2 b0 = a.x * wyp, b1 = a.y * wyp;
                                 const f32x2 c00 = b0.x * wzp, c01 = b0.y * wzp, c10 = b1.x * wzp, c11 = b1.y * wzp;
-                                int *q = &acc[(((cx << 4) + cx + cy) << 6) + cz];
+                                int *q = &acc[tile_cell_dword(cx, cy, cz)];
                                 atomicAdd(q, cvt_round_i32(c00.x));
                                 atomicAdd(q + 1, cvt_round_i32(c00.y));
                                 atomicAdd(q + ALZ, cvt_round_i32(c01.x));

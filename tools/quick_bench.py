@@ -9,6 +9,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tomography_alignment_amd import _lib  # noqa: E402
+if os.environ.get("TOMO_AB_LIB"):              # A/B runs: another build of the library (development aid only)
+    _lib.LIB_PATH = os.environ["TOMO_AB_LIB"]
 from tomography_alignment_amd.backend import HipBackend  # noqa: E402
 from tomography_alignment_amd.utilities.geometry import Geometry  # noqa: E402
 
