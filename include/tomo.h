@@ -96,6 +96,8 @@ TOMO_API int tomo_sync(tomo_ctx *ctx);
  *   "tile_flat"   1 (default): untilted projections (alpha = beta = 0, detector-z pitch 1) take the flat tile kernels
  *   "fwd_flat_ztiles" 2 (default): the flat forward kernel owns two z-adjacent tiles per work-group and builds each detector
  *                 row's sample table once for both; 1: one tile per work-group
+ *   "fwd_flat_wide" 0 (default); 1: measurement variant of the flat forward with a 32 x 16 x 63 tile footprint and one image
+ *                 per work-group (half the tile crossings, hence half the sinogram atomics; whole-volume calls only)
  *   "adj_flat_gather" 1 (default): untilted projections on a unit lattice (detector pitch = step = voxel) take the gather-form
  *                 adjoint (accumulators in registers, no atomics) instead of the LDS-atomic flat tile kernel
  *   "reuse_staged_volume" 1: the caller vouches that the volume passed to tomo_proj_grad / tomo_cost_grad / the ray-driven

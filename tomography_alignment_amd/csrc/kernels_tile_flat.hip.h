@@ -16,13 +16,13 @@
 // cells can fall into the tile's 16 x 16 footprint -- the row's line (tile-relative, sample 0 at (cbx, cby), direction (fdx, fdy))
 // clipped against the footprint widened by 2e-2 (conservative float32; exact ownership is decided per sample from the
 // fixed-point position).  One row per LANE; the callers broadcast the results with v_readlane.
-__device__ __forceinline__ void flat_row_range(float cbx, float cby, float fdx, float fdy, int n, bool row_ok, int &jlo, int &jhi)
+__device__ __forceinline__ void flat_row_range(float cbx, float cby, float fdx, float fdy, int n, bool row_ok, int &jlo, int &jhi, float xext = (float)ATX)
 {
     float t0 = 0.f, t1 = (float)(n - 1);
     if (fdx != 0.f) {
-        const float inv = 1.f / fdx, ta = (-2e-2f - cbx) * inv, tb = ((float)ATX + 2e-2f - cbx) * inv;
+        const float inv = 1.f / fdx, ta = (-2e-2f - cbx) * inv, tb = (xext + 2e-2f - cbx) * inv;
         t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
-    } else if (cbx < -2e-2f || cbx >= (float)ATX + 2e-2f) { t0 = 1.f; t1 = 0.f; }
+    } else if (cbx < -2e-2f || cbx >= xext + 2e-2f) { t0 = 1.f; t1 = 0.f; }
     if (fdy != 0.f) {
         const float inv = 1.f / fdy, ta = (-2e-2f - cby) * inv, tb = ((float)ATY + 2e-2f - cby) * inv;
         t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
@@ -236,22 +236,26 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
 // number of waves per CU as two 8-wave work-groups of the one-image kernel.
 // ------------------------------------------------------------------------------------------------
 #define FZ_WAVES 16
-template <int NZT>
+// TX = x width of the tile footprint: 16 (with NZT = 2 z-stacked images: the default) or 32 (with NZT = 1: the "32 x 16 footprint"
+// of DESIGN.md section 4, built in round 3 to MEASURE what halving the tile crossings -- hence the float atomics -- costs in the
+// sample loop, whose per-entry broadcasts then serve one image instead of two; option fwd_flat_wide).
+template <int NZT, int TX = ATX>
 __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
                                                               const float *__restrict__ vol, TomoGeomC g, int tile_x0)
 {
     // the images of the NZT stacked tiles are INTERLEAVED per (x, y) cell: [x][y][tile][64 planes] -- every corner of every image of a
     // sample then lies within ds_read2st64_b32's offset range (units of 256 B, < 256) of ONE address register
-    __shared__ float img[ALX * ALY * NZT * FLZ];
+    static_assert((TX + 1) * ALY * NZT * FLZ * 4 <= 160 * 1024, "LDS");
+    __shared__ float img[(TX + 1) * ALY * NZT * FLZ];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int z0 = -1 + (int)blockIdx.x * (NZT * FTZ), y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + ((int)blockIdx.z + tile_x0) * ATX;
+    const int z0 = -1 + (int)blockIdx.x * (NZT * FTZ), y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + ((int)blockIdx.z + tile_x0) * TX;
     bool live[NZT];
     bool any_live = false;
 #pragma unroll
     for (int k = 0; k < NZT; ++k) {
         bool any_nz = false;
-        for (int e = threadIdx.x; e < ALX * ALY * FLZ; e += FZ_WAVES * 64) {
+        for (int e = threadIdx.x; e < (TX + 1) * ALY * FLZ; e += FZ_WAVES * 64) {
             const int lz = e % FLZ, t2 = e / FLZ, ly = t2 % ALY, lx = t2 / ALY;
             const int gx = x0 + lx, gy = y0 + ly, gz = z0 + k * FTZ + lz;
             float v = 0.f;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
         any_live |= live[k];
     }
     if (!any_live) return;
-    const float bcx = (float)x0 + 0.5f * ATX, bcy = (float)y0 + 0.5f * ATY;
+    const float bcx = (float)x0 + 0.5f * TX, bcy = (float)y0 + 0.5f * ATY;
     const int64_t orgx = (int64_t)x0 << 32, orgy = (int64_t)y0 << 32;
     const size_t n_det = (size_t)g.ndx * g.ndz;
     const float two_m32 = 2.3283064365386963e-10f;
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
         const float qx = bcx - (float)c.p0[0], qy = bcy - (float)c.p0[1];
         const float m00 = (float)c.minv[0][0], m01 = (float)c.minv[0][1];
         const float ixc = m00 * qx + m01 * qy;
-        const float ixr = fabsf(m00) * (0.5f * ATX) + fabsf(m01) * (0.5f * ATY) + 2e-2f;
+        const float ixr = fabsf(m00) * (0.5f * TX) + fabsf(m01) * (0.5f * ATY) + 2e-2f;
         const int ix_lo = max(0, (int)ceilf(fmaxf(ixc - ixr, -1.f)));
         const int ix_hi = min(g.ndx - 1, (int)floorf(fminf(ixc + ixr, (float)g.ndx)));
         if (ix_lo > ix_hi) continue;
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
             int v_jlo, v_jhi;
             {
                 const int rix = ix_lo + r0 + lane;
-                flat_row_range(fp0x + (float)rix * fux, fp0y + (float)rix * fuy, fdx, fdy, c.n, rix <= ix_hi, v_jlo, v_jhi);
+                flat_row_range(fp0x + (float)rix * fux, fp0y + (float)rix * fuy, fdx, fdy, c.n, rix <= ix_hi, v_jlo, v_jhi, (float)TX);
             }
             const int r_end = min(64, n_rows_w - r0);
             int64_t rbx = c.fp0[0] + (int64_t)(ix_lo + r0) * k_fux - orgx, rby = c.fp0[1] + (int64_t)(ix_lo + r0) * k_fuy - orgy;
@@ -326,7 +330,8 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
                     asm volatile("" : "+s"(ux), "+s"(uy));
                     const int64_t px = add64_vs(ldx, ux), py = add64_vs(ldy, uy);
                     const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32);
-                    const unsigned long long own_m = __builtin_amdgcn_ballot_w64((lx | ly) < (unsigned)ATX) & __builtin_amdgcn_ballot_w64(jc + lane < min(jhi, jc + 60));
+                    const unsigned long long own_m = (TX == ATY ? __builtin_amdgcn_ballot_w64((lx | ly) < (unsigned)ATY) : (__builtin_amdgcn_ballot_w64(lx < (unsigned)TX) & __builtin_amdgcn_ballot_w64(ly < (unsigned)ATY))) &
+                                                     __builtin_amdgcn_ballot_w64(jc + lane < min(jhi, jc + 60));
                     const unsigned t_e = (__umul24(lx, ALY * NZT * FLZ) + __umul24(ly, NZT * FLZ)) * 4u;
                     const float wx = (float)(unsigned)px * two_m32, wy = (float)(unsigned)py * two_m32;
                     const float t_w11 = wx * wy, t_w10 = wx - t_w11, t_w01 = wy - t_w11, t_w00 = 1.f - wx - t_w01;
