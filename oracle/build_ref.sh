@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # TEST INFRASTRUCTURE - builds the *untouched* reference Fortran where it lies
-# under /root/reference into oracle/_ref/ (git-ignored AND listed in .gpurunignore: compiled reference
-# objects stay in the authoring container; the GPU box gets the oracle restatement and the committed fixtures only).
+# under /root/reference into oracle/_ref/ (git-ignored, so the history stays source-only; NOT gpurun-ignored since round 3:
+# the built binaries travel to the GPU box like our own .so files, where bench.py times libref_mf.so as `cpu_baseline.reference`).
 # Nothing from the reference is copied into the repo; only compiled objects and
 # f2py-GENERATED wrapper sources land in oracle/_ref/.
 #
