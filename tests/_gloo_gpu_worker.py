@@ -1,0 +1,110 @@
+"""Worker of tests/test_gpu_dist.py: one rank of an angle-sharded SIRT run with the REAL HIP backend (every rank opens its own
+context on GPU 0) and a host-staged torch.distributed/gloo communicator standing in for RCCL (two RCCL ranks cannot share one GPU;
+the 1-GPU boxes of this pool cannot run RCCL with more than one rank).  What this exercises that nothing else does: the sharded
+solver's slab pipeline (tomo_adjoint_xslab / tomo_forward_xslab / tomo_vec_update_acc on views) with world size 2, i.e. partial
+volumes that really differ between ranks and are summed by a collective.  Rank 0 writes the results."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+
+class HostStagedComm(object):
+    """RcclComm's method set over gloo: device buffers are all-reduced through the host.  The asynchronous forms complete at once."""
+
+    def __init__(self, ctx):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.size = dist.get_rank(), dist.get_world_size()
+        self.ctx = ctx
+        self.n_vol_allreduce = self.n_slab_allreduce = self.n_wait = 0
+
+    def _ar(self, buf):
+        import torch
+        if buf.size:
+            h = buf.download()
+            t = torch.from_numpy(h)
+            self.dist.all_reduce(t)
+            buf.upload(h)
+        return buf
+
+    def allreduce_sum_(self, buf):
+        self.n_vol_allreduce += 1
+        return self._ar(buf)
+
+    def allreduce_sum_async(self, buf):
+        self.n_slab_allreduce += 1
+        return self._ar(buf)
+
+    def wait_next(self):
+        self.n_wait += 1
+
+    def join(self):
+        pass
+
+    def allreduce_scalar(self, v):
+        import torch
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        self.dist.all_reduce(t)
+        return float(t[0])
+
+    def allreduce_max(self, v):
+        import torch
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def main(out_path):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="env://")
+    from tomography_alignment_amd import _lib
+    from tomography_alignment_amd.backend import HipBackend
+    from tomography_alignment_amd.recon import sirt_mpi
+    from tomography_alignment_amd.utilities.geometry import Geometry
+
+    ctx = _lib.Context(0)
+    comm = HostStagedComm(ctx)
+    shape, ndet, n_proj = (80, 40, 48), (72, 56), 12            # 6 tile columns; ragged in every axis
+    rng = np.random.default_rng(11)
+    x = np.zeros(shape, np.float32)
+    x[10:70, 6:34, 8:40] = rng.uniform(0.2, 1.0, (60, 28, 32)).astype(np.float32)
+    phi = np.linspace(0.05, np.pi - 0.05, n_proj)
+    cor = np.zeros((n_proj, 3))
+    cor[:, 0] = rng.uniform(-1, 1, n_proj)                       # per-angle COR shifts must follow their angles into the shards
+    geo = Geometry(n_proj, np.array(shape), np.ones(3), np.array(ndet), np.ones(2), cor_shift=cor)
+    out = {}
+    for tag, tilt in (("flat", 0.0), ("tilted", 1.0)):
+        alpha, beta = np.deg2rad(tilt * rng.uniform(-1.5, 1.5, n_proj)), np.deg2rad(tilt * rng.uniform(-1.5, 1.5, n_proj))
+        xyz = np.zeros((n_proj, 3))
+        xyz[:, 0], xyz[:, 2] = rng.uniform(-2, 2, n_proj), rng.uniform(-2, 2, n_proj)
+        ang = np.array([phi, alpha, beta]).T
+        # measured projections: every rank computes the whole set with an unsharded operator (same on all ranks)
+        full = HipBackend(geo, ctx=ctx)
+        b = full.forward(_lib.poses_array(phi, alpha, beta, xyz, cor), full.upload(x), full.empty(n_proj * ndet[0] * ndet[1])).download().reshape(n_proj, -1)
+        mine = np.array_split(np.arange(n_proj), comm.size)[comm.rank]
+        for mode in ("pipelined", "plain"):
+            comm.force_pipeline = mode == "pipelined"
+            s = sirt_mpi.SIRT(comm, geo, b.copy(), ang, xyz, options={"_backend": HipBackend(sirt_mpi.SIRT._shard_geometry(geo, mine), ctx=ctx), "ground_truth": x})
+            if mode == "plain":
+                s.n_pipeline_slabs = 1
+            v0, s0 = comm.n_vol_allreduce, comm.n_slab_allreduce
+            rec, err = s.run_main_iteration(niter=5, positivity=True)
+            out["%s_%s_rec" % (tag, mode)], out["%s_%s_err" % (tag, mode)] = rec, err
+            out["%s_%s_nvol" % (tag, mode)], out["%s_%s_nslab" % (tag, mode)] = comm.n_vol_allreduce - v0, comm.n_slab_allreduce - s0
+            out["%s_%s_pipelined" % (tag, mode)] = s._iter_pipelined
+    if comm.rank == 0:
+        np.savez(out_path, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

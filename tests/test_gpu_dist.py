@@ -1,0 +1,55 @@
+"""World size 2 ON THE GPU: two processes share GPU 0, each with its own context and the real HIP backend; the volume all-reduces
+go through the host over torch.distributed/gloo (tests/_gloo_gpu_worker.py explains why not RCCL).  The angle-sharded SIRT --
+slab pipeline and plain sequence -- must give the world-size-1 answer."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rel_max
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(world, out):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_gpu_worker.py"), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    try:
+        for p in procs:
+            logs.append(p.communicate(timeout=300)[0].decode())
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                      # exactly the processes started here
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log
+    return np.load(out)
+
+
+@pytest.mark.timeout(900)
+def test_sharded_sirt_world_2_on_the_gpu(tmp_path):
+    one = _run(1, str(tmp_path / "g1.npz"))
+    two = _run(2, str(tmp_path / "g2.npz"))
+    for tag in ("flat", "tilted"):
+        ref = one["%s_plain_rec" % tag]
+        for w, name in ((one, "world 1"), (two, "world 2")):
+            for mode in ("pipelined", "plain"):
+                assert rel_max(w["%s_%s_rec" % (tag, mode)], ref) < 1e-5, (tag, name, mode)
+                assert np.allclose(w["%s_%s_err" % (tag, mode)], one["%s_plain_err" % tag], rtol=1e-5), (tag, name, mode)
+            assert bool(w["%s_pipelined_pipelined" % tag]) and not bool(w["%s_plain_pipelined" % tag])
+        # 5 iterations (counted after the constructor's all-reduce of V): pipelined = 6 slab all-reduces per iteration and no
+        # whole-volume one; plain = one whole-volume all-reduce per iteration
+        assert int(two["%s_pipelined_nvol" % tag]) == 0 and int(two["%s_pipelined_nslab" % tag]) == 5 * 6
+        assert int(two["%s_plain_nvol" % tag]) == 5 and int(two["%s_plain_nslab" % tag]) == 0
+        assert one["%s_plain_err" % tag][-1] < one["%s_plain_err" % tag][0]
