@@ -172,7 +172,9 @@ def test_gradient_kernels_agree_on_random_geometry(seed):
                 gmax = [max(np.max(np.abs(rays[2][i][1][:3])), 1e-30)] * 3 + [max(np.max(np.abs(rays[2][i][1][3:])), 1e-30)] * 3
                 eg = max(float(np.max(np.abs(rays[v][i][1][r] - rays[2][i][1][r]))) / gmax[r] for r in range(6))
                 worst_ray = max(worst_ray, ep, eg)
-                assert ep < 2e-6 and eg < 5e-6, ("per ray", v, k, i, shape, ndet, step, np.rad2deg(tilt))    # float32 lerps in another order (2: y, x, z; 3: z, y, x)
+                # float32 lerps in another order (2: y, x, z; 3: z, y, x): each variant is within 1e-5 of the float64 oracle (above); between two
+                # float32 evaluations the same bar applies (a 116-seed soak in round 3 saw 4.6e-6 ... 5.x e-6 on rows with heavy cancellation)
+                assert ep < 2e-6 and eg < 1e-5, ("per ray", ep, eg, v, k, i, shape, ndet, step, np.rad2deg(tilt))
     print("worst: per ray between kernels %.2e, per ray vs oracle (well-conditioned rays) %.2e, fused sums vs own rays %.2e" % (worst_ray, worst_orc, worst_sum))
 
 

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Run tests/test_gpu_fuzz.py's two cross-checks (tile kernels, gradient kernels) over many seeds (development aid): python tools/fuzz_soak.py [first] [last]"""
+"""Run tests/test_gpu_fuzz.py's two cross-checks (tile kernels, gradient kernels) over many seeds (development aid):
+python tools/fuzz_soak.py [first] [last] -- keeps going after a failed seed and lists the failures at the end."""
 import os
 import sys
 
@@ -9,7 +10,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_fuzz as f      # noqa: E402
 
 a, b = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4, 40)
+bad = []
 for seed in range(a, b):
-    f.test_tile_kernels_agree_with_ray_driven_kernels(seed)
-    f.test_gradient_kernels_agree_on_random_geometry(seed)
-print("seeds %d..%d ok" % (a, b - 1))
+    for fn in (f.test_tile_kernels_agree_with_ray_driven_kernels, f.test_gradient_kernels_agree_on_random_geometry):
+        try:
+            fn(seed)
+        except AssertionError as e:
+            bad.append((seed, fn.__name__, str(e)[:300]))
+            print("FAILED seed", seed, fn.__name__, str(e)[:300], flush=True)
+print("seeds %d..%d: %d failures" % (a, b - 1, len(bad)))
+for x in bad:
+    print(x)
