@@ -96,6 +96,9 @@ TOMO_API int tomo_sync(tomo_ctx *ctx);
  *   "tile_flat"   1 (default): untilted projections (alpha = beta = 0, detector-z pitch 1) take the flat tile kernels
  *   "fwd_flat_ztiles" 2 (default): the flat forward kernel owns two z-adjacent tiles per work-group and builds each detector
  *                 row's sample table once for both; 1: one tile per work-group
+ *   "fwd_flat_tab" 1 (default): the two-z-tile flat forward keeps each row's sample table in LDS and the two images interleaved
+ *                 per plane (k_fwd_flat_tab: 4 ds_read_b64 + 4 packed FMAs per sample, no cross-lane broadcasts); 0: the round-2
+ *                 kernel (entries broadcast with v_readlane)
  *   "fwd_flat_wide" 0 (default); 1: measurement variant of the flat forward with a 32 x 16 x 63 tile footprint and one image
  *                 per work-group (half the tile crossings, hence half the sinogram atomics; whole-volume calls only)
  *   "adj_flat_gather" 1 (default): untilted projections on a unit lattice (detector pitch = step = voxel) take the gather-form

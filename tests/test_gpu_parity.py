@@ -10,6 +10,7 @@ from conftest import golden, rel_max, rel_l2, g10_case, grad_dev_per_ray
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
+TAB_DEFAULT = 1      # the library's default for option fwd_flat_tab
 
 
 def geo_pair(n_proj, N, cor_shift=None, step=1.0, ndet=None, shape=None):
@@ -344,18 +345,21 @@ def test_untilted_poses_take_the_flat_tile_kernels(PM, orc, shape, ndet):
     assert rel_max(res[1, 1][1], res[1, 0][1]) < 2e-6 and rel_max(res[1, 1][0], res[1, 0][0]) < 2e-6
 
 
-@pytest.mark.parametrize("shape,ndet", [((40, 36, 130), (44, 150)), ((70, 33, 64), (70, 64)), ((33, 20, 70), (30, 80))])
-def test_flat_forward_wide_footprint_variant(PM, orc, shape, ndet):
-    """The 32 x 16-footprint measurement variant of the flat forward (option fwd_flat_wide, DESIGN.md section 4 "forward write
-    amplification") computes the same projections as the default two-z-tile kernel and as the oracle -- including volumes whose
-    x extent is not a multiple of 32, exactly degenerate angles, translations and COR shifts."""
+@pytest.mark.parametrize("shape,ndet,step", [((40, 36, 130), (44, 150), 1.0), ((70, 33, 64), (70, 64), 1.0), ((33, 20, 70), (30, 80), 1.0),
+                                             ((40, 36, 130), (44, 150), 0.5), ((20, 24, 200), (20, 190), 0.75)])
+def test_flat_forward_kernel_variants(PM, orc, shape, ndet, step):
+    """The variants of the flat forward -- the round-2 kernel (entries broadcast with v_readlane, option fwd_flat_tab = 0), the round-3
+    kernel (sample table in LDS, the two images interleaved per plane: fwd_flat_tab = 1) and the 32 x 16-footprint measurement variant
+    (fwd_flat_wide, DESIGN.md section 4 "forward write amplification") -- compute the same projections as each other and as the
+    oracle: volumes whose x extent is not a multiple of 32, exactly degenerate angles, translations, COR shifts, and steps below a
+    voxel (rows with more samples in a tile than one pass of the table holds)."""
     rng = np.random.default_rng(7)
     n_proj = 5
     phi = np.array([0.0, 0.37, np.pi / 2, 2.2, np.pi])
     xyz = rng.uniform(-3, 3, (n_proj, 3))
     cor = np.zeros((n_proj, 3))
     cor[:, 0] = rng.uniform(-1.5, 1.5, n_proj)
-    geo, og = geo_pair(n_proj, None, shape=shape, ndet=ndet, cor_shift=cor)
+    geo, og = geo_pair(n_proj, None, shape=shape, ndet=ndet, cor_shift=cor, step=step)
     x = rng.uniform(0.1, 1.0, shape).astype(np.float32)
     P = PM(geo)
     A = P.projection_matrix(phi=phi, xyz_shift=xyz)
@@ -363,13 +367,18 @@ def test_flat_forward_wide_footprint_variant(PM, orc, shape, ndet):
     want = orc.forward(og, x, phi=phi, xyz_shift=xyz).ravel()
     ctx.profile_reset()
     ctx.profile_enable(True)
-    f_def = A.dot(x.ravel())
+    res = {}
+    for tab in (0, 1):
+        ctx.set_option("fwd_flat_tab", tab)
+        res[tab] = A.dot(x.ravel())
     ctx.set_option("fwd_flat_wide", 1)
     f_wide = A.dot(x.ravel())
     ctx.set_option("fwd_flat_wide", 0)
+    ctx.set_option("fwd_flat_tab", TAB_DEFAULT)
     ctx.profile_enable(False)
-    assert ctx.profile_get("k_fwd_tile_flat")[0] == 2 and ctx.profile_get("k_fwd_tile")[0] == 0
-    assert rel_max(f_def, want) < TOL and rel_max(f_wide, want) < TOL and rel_max(f_wide, f_def) < 2e-6
+    assert ctx.profile_get("k_fwd_tile_flat")[0] == 3 and ctx.profile_get("k_fwd_tile")[0] == 0
+    assert rel_max(res[0], want) < TOL and rel_max(res[1], want) < TOL and rel_max(f_wide, want) < TOL
+    assert rel_max(res[1], res[0]) < 2e-6 and rel_max(f_wide, res[0]) < 2e-6
 
 
 def test_mixed_tilted_and_untilted_call(PM, orc):

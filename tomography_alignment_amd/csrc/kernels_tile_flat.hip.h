@@ -443,3 +443,148 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Forward flat kernel, round-3 form: sample table in LDS + image PAIRS.
+// Round 2 measured two halves of this separately and each moved the bound to the other unit: (a) the per-row sample table in a
+// wave-private LDS table (no v_readlane): 0.523 ms/angle, LDS-bound at 5 + 16 LDS clk per entry; (b) data reads as ds_read_b64
+// (half the LDS cycles) with the table still broadcast by five v_readlane per entry: 0.444 vs 0.448, VALU-bound.  Together:
+//   * the two z-stacked images are interleaved per PLANE, [x][y][64 planes][image]: the values a lane needs from both images for a
+//     corner are one aligned 8-byte word -> 4 ds_read_b64 per entry at immediate offsets of ONE address (y + 1: +512 B, x + 1:
+//     +8704 B), 2 LDS clk each, the register pair (image 0, image 1) feeds v_pk_fma_f32 directly;
+//   * entries are fetched four at a time with broadcast ds_read_b128 (1 for the 4 addresses + 4 for the weights = 5 LDS clk per
+//     entry), their weights arrive in VGPRs: 4 v_pk_fma_f32 + 1 v_add_u32 per entry and lane, no v_readlane.
+// LDS 13 clk and VALU ~6 clk per entry and CU against 17.6 / ~12 (+ set-up) of k_fwd_flat_z<2>.
+// Same sums as k_fwd_flat_z<2>, in the same order per row (entries ascending, four accumulator pairs -> two).
+// ------------------------------------------------------------------------------------------------
+#define FT2_TAB 32
+#define FT2_TAB_ALLOC (FT2_TAB + 4)
+__global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
+                                                                const float *__restrict__ vol, TomoGeomC g, int tile_x0)
+{
+    __shared__ __attribute__((aligned(16))) float img[ALX * ALY * FLZ * 2];                  // [x][y][plane][image]
+    __shared__ float4 tab_w[FZ_WAVES * FT2_TAB_ALLOC];
+    __shared__ __attribute__((aligned(16))) unsigned tab_e[FZ_WAVES * FT2_TAB_ALLOC];
+    static_assert(sizeof(float) * ALX * ALY * FLZ * 2 + 20 * FZ_WAVES * FT2_TAB_ALLOC <= 160 * 1024, "LDS");
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int z0 = -1 + (int)blockIdx.x * (2 * FTZ), y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + ((int)blockIdx.z + tile_x0) * ATX;
+    bool live[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        bool any_nz = false;
+        for (int e = threadIdx.x; e < ALX * ALY * FLZ; e += FZ_WAVES * 64) {
+            const int lz = e % FLZ, t2 = e / FLZ, ly = t2 % ALY, lx = t2 / ALY;
+            const int gx = x0 + lx, gy = y0 + ly, gz = z0 + k * FTZ + lz;
+            float v = 0.f;
+            if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz) v = vol[((size_t)gx * g.ny + gy) * g.nz + gz];
+            img[e * 2 + k] = v;
+            any_nz |= (v != 0.f);
+        }
+        live[k] = __syncthreads_or(any_nz) != 0;                      // an all-zero tile contributes nothing to any ray
+    }
+    if (!(live[0] || live[1])) return;
+    const float bcx = (float)x0 + 0.5f * ATX, bcy = (float)y0 + 0.5f * ATY;
+    const int64_t orgx = (int64_t)x0 << 32, orgy = (int64_t)y0 << 32;
+    const size_t n_det = (size_t)g.ndx * g.ndz;
+    const float two_m32 = 2.3283064365386963e-10f;
+    const unsigned lane8 = (unsigned)min(lane, FLZ - 1) * 8u;
+    float4 *const tw = tab_w + wv * FT2_TAB_ALLOC;
+    unsigned *const te = tab_e + wv * FT2_TAB_ALLOC;
+    const lds_cfloat *const img_l = (const lds_cfloat *)img;            // explicit LDS pointer (address space 3): ds_read, not flat loads
+
+    for (int ip = wv; ip < n_proj; ip += FZ_WAVES) {               // one wave owns a whole (tile stack, projection)
+        const AdjC &c = pcs[ip];
+        const int p0z_i = (int)(c.fp0[2] >> 32);
+        const float wcz = (float)(unsigned)c.fp0[2] * two_m32, wfz = 1.f - wcz;
+        bool zuse[2], ray_ok[2];
+        const int iz0 = z0 - p0z_i + lane;                             // this lane's ray in the lower tile; + FTZ in the upper
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int izoff = z0 + k * FTZ - p0z_i;
+            zuse[k] = live[k] && !(izoff + FTZ <= 0 || izoff >= g.ndz);
+            const int iz = iz0 + k * FTZ;
+            ray_ok[k] = zuse[k] && lane < FTZ && iz >= 0 && iz < g.ndz;
+        }
+        if (!(zuse[0] || zuse[1])) continue;
+        const float qx = bcx - (float)c.p0[0], qy = bcy - (float)c.p0[1];
+        const float m00 = (float)c.minv[0][0], m01 = (float)c.minv[0][1];
+        const float ixc = m00 * qx + m01 * qy;
+        const float ixr = fabsf(m00) * (0.5f * ATX) + fabsf(m01) * (0.5f * ATY) + 2e-2f;
+        const int ix_lo = max(0, (int)ceilf(fmaxf(ixc - ixr, -1.f)));
+        const int ix_hi = min(g.ndx - 1, (int)floorf(fminf(ixc + ixr, (float)g.ndx)));
+        if (ix_lo > ix_hi) continue;
+        const int n_rows_w = ix_hi - ix_lo + 1;
+        const float fp0x = (float)c.p0[0] - (float)x0, fp0y = (float)c.p0[1] - (float)y0;
+        const float fux = (float)c.u[0], fuy = (float)c.u[1], fdx = (float)c.d[0], fdy = (float)c.d[1];
+        int64_t ldx = (int64_t)lane * c.fd[0], ldy = (int64_t)lane * c.fd[1];
+        int64_t k_fux = c.fu[0], k_fuy = c.fu[1], k_fdx = c.fd[0], k_fdy = c.fd[1];
+        asm volatile("" : "+v"(ldx), "+v"(ldy));                       // see k_tile_flat: keep the row loop's inputs in registers
+        asm volatile("" : "+s"(k_fux), "+s"(k_fuy), "+s"(k_fdx), "+s"(k_fdy));
+        float *const proj_c = proj + (size_t)c.slot * n_det + iz0;
+
+        for (int r0 = 0; r0 < n_rows_w; r0 += 64) {
+            int v_jlo, v_jhi;
+            {
+                const int rix = ix_lo + r0 + lane;
+                flat_row_range(fp0x + (float)rix * fux, fp0y + (float)rix * fuy, fdx, fdy, c.n, rix <= ix_hi, v_jlo, v_jhi);
+            }
+            const int r_end = min(64, n_rows_w - r0);
+            int64_t rbx = c.fp0[0] + (int64_t)(ix_lo + r0) * k_fux - orgx, rby = c.fp0[1] + (int64_t)(ix_lo + r0) * k_fuy - orgy;
+            float *pr = proj_c + (size_t)(ix_lo + r0) * g.ndz;
+            for (int r = 0; r < r_end; ++r, rbx += k_fux, rby += k_fuy, pr += g.ndz) {
+                const int jlo = __builtin_amdgcn_readlane(v_jlo, r), jhi = __builtin_amdgcn_readlane(v_jhi, r);
+                if (jhi <= jlo) continue;
+                f32x2 Pa = {0.f, 0.f}, Pb = {0.f, 0.f};               // .x: image 0 (lower tile), .y: image 1
+                for (int jc = jlo; jc < jhi; jc += FT2_TAB) {
+                    int64_t ux = rbx + (int64_t)jc * k_fdx, uy = rby + (int64_t)jc * k_fdy;
+                    asm volatile("" : "+s"(ux), "+s"(uy));
+                    const int64_t px = add64_vs(ldx, ux), py = add64_vs(ldy, uy);
+                    const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32);
+                    const unsigned long long om = __builtin_amdgcn_ballot_w64((lx | ly) < (unsigned)ATX) &
+                                                  __builtin_amdgcn_ballot_w64(jc + lane < min(jhi, jc + FT2_TAB));
+                    if (om == 0) continue;
+                    const unsigned t_e = (__umul24(lx, ALY * FLZ * 2) + __umul24(ly, FLZ * 2)) * 4u;      // byte offset of cell (lx, ly), plane 0, image 0
+                    const float wx = (float)(unsigned)px * two_m32, wy = (float)(unsigned)py * two_m32;
+                    const float t_w11 = wx * wy, t_w10 = wx - t_w11, t_w01 = wy - t_w11, t_w00 = 1.f - wx - t_w01;
+                    // the owned samples of a row are CONTIGUOUS lanes first .. first + n_own - 1 (see k_fwd_flat_z): entry i of the table =
+                    // lane first + i; three zero entries behind them let the loop run in unmasked groups of four.  LDS operations of
+                    // one wave execute in order: no barrier between these writes and the reads below, nor against the previous chunk's.
+                    const int n_own = (int)__builtin_popcountll(om);
+                    const int first = (int)__builtin_ctzll(om);
+                    const unsigned slot = (unsigned)(lane - first);
+                    if (slot < (unsigned)n_own) {
+                        tw[slot] = make_float4(t_w00, t_w01, t_w10, t_w11);
+                        te[slot] = t_e;
+                    } else if (slot < (unsigned)(n_own + 3)) {
+                        tw[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        te[slot] = 0u;
+                    }
+                    for (int j4 = 0; j4 < n_own; j4 += 4) {                                    // wave-uniform
+                        const uint4 e = *(const uint4 *)(te + j4);                           // broadcast reads
+                        const float4 wa = tw[j4], wb = tw[j4 + 1], wc = tw[j4 + 2], wd = tw[j4 + 3];
+#define FT2_ENTRY(E, W)                                                                                                    \
+                        {                                                                                                   \
+                            /* explicit LDS pointer; volatile keeps four ds_read_b64 (2 LDS clk each): merged into ds_read2st64_b64 */ \
+                            /* they cost 8 clk per pair (MI355X_MICROARCH.md, LDS table)                                           */ \
+                            typedef __attribute__((address_space(3))) const volatile f32x2 lds_v2;                          \
+                            const __attribute__((address_space(3))) char *q_ = (const __attribute__((address_space(3))) char *)img_l + ((E) + lane8); \
+                            const f32x2 v00 = *(lds_v2 *)(q_), v01 = *(lds_v2 *)(q_ + FLZ * 8);                             \
+                            const f32x2 v10 = *(lds_v2 *)(q_ + ALY * FLZ * 8), v11 = *(lds_v2 *)(q_ + (ALY + 1) * FLZ * 8); \
+                            Pa += (W).x * v00; Pb += (W).y * v01; Pa += (W).z * v10; Pb += (W).w * v11;                     \
+                        }
+                        FT2_ENTRY(e.x, wa) FT2_ENTRY(e.y, wb) FT2_ENTRY(e.z, wc) FT2_ENTRY(e.w, wd)
+#undef FT2_ENTRY
+                    }
+                }
+                const f32x2 Pt = Pa + Pb;
+                const float S[2] = {Pt.x, Pt.y};
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (!zuse[k]) continue;
+                    const float Sp1 = __shfl_down(S[k], 1, 64);                // plane lane+1
+                    if (ray_ok[k]) atomicAdd(pr + k * FTZ, wfz * S[k] + wcz * Sp1);
+                }
+            }
+        }
+    }
+}

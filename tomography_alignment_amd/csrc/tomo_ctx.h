@@ -62,6 +62,7 @@ struct tomo_ctx {
     int grad_variant = 4;     // 1 plain, 2 eight dword gathers + packed lerps, 3 four gathers + DPP neighbour shift, 4 (default) 2 or 3 per pose by tilt
     int tile_flat = 1;      // 1: untilted projections take the flat tile kernels
     int adj_flat_gather = 1;  // 1: untilted unit lattices take the gather-form adjoint (k_adj_gather_flat) instead of the LDS-atomic flat kernel
+    int fwd_flat_tab = 1;     // 1 (default): the flat forward with the sample table in LDS and the two images interleaved per plane (k_fwd_flat_tab); 0: the round-2 kernel (k_fwd_flat_z<2>: entries broadcast with v_readlane)
     int fwd_flat_wide = 0;    // 1: measurement variant of the flat forward -- 32 x 16 x 63 footprint, one image per work-group (k_fwd_flat_z<1, 32>)
     int fwd_flat_ztiles = 2;  // 2: the flat forward processes two z-adjacent tiles per work-group (k_fwd_flat_z<2>); 1: one tile (k_tile_flat<true>)
     // timing / profiling

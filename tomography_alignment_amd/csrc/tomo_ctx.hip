@@ -145,6 +145,7 @@ extern "C" int tomo_set_option(tomo_ctx *ctx, const char *key, int value)
     else if (!strcmp(key, "adj_flat_gather")) ctx->adj_flat_gather = value;
     else if (!strcmp(key, "fwd_flat_ztiles")) ctx->fwd_flat_ztiles = value;
     else if (!strcmp(key, "fwd_flat_wide")) ctx->fwd_flat_wide = value;
+    else if (!strcmp(key, "fwd_flat_tab")) ctx->fwd_flat_tab = value;
     else if (!strcmp(key, "reuse_staged_volume")) ctx->reuse_staged = value;
     else return tomo_fail(ctx, TOMO_ERR_ARG, std::string("unknown option ") + key);
     return TOMO_OK;
