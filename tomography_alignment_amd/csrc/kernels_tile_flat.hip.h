@@ -457,7 +457,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
 // Same sums as k_fwd_flat_z<2>, in the same order per row (entries ascending, four accumulator pairs -> two).
 // ------------------------------------------------------------------------------------------------
 #define FT2_TAB 32
-#define FT2_TAB_ALLOC (FT2_TAB + 4)
+#define FT2_TAB_ALLOC (FT2_TAB + 4)      // + 3 zero entries behind the owners (the loop runs in unmasked groups of four)
 __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
                                                                 const float *__restrict__ vol, TomoGeomC g, int tile_x0)
 {
@@ -552,13 +552,14 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
                     const int n_own = (int)__builtin_popcountll(om);
                     const int first = (int)__builtin_ctzll(om);
                     const unsigned slot = (unsigned)(lane - first);
-                    if (slot < (unsigned)n_own) {
-                        tw[slot] = make_float4(t_w00, t_w01, t_w10, t_w11);
-                        te[slot] = t_e;
-                    } else if (slot < (unsigned)(n_own + 3)) {
-                        tw[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        te[slot] = 0u;
+                    if (slot < (unsigned)(n_own + 3)) {                                      // ONE masked pair of writes: the three lanes behind the owners write zeros
+                        const bool mine = slot < (unsigned)n_own;
+                        tw[slot] = make_float4(mine ? t_w00 : 0.f, mine ? t_w01 : 0.f, mine ? t_w10 : 0.f, mine ? t_w11 : 0.f);
+                        te[slot] = mine ? t_e : 0u;
                     }
+                    // groups of four entries: 1 + 4 broadcast ds_read_b128 (addresses, weights), then per entry 4 ds_read_b64 + 4 packed FMAs.
+                    // (Measured and dropped in round 3: fetching the next group's table words before this group's data reads are consumed
+                    // -- with copies 37, with two named register sets 63 VALU per 8 entries and a branch: 0.375 against 0.356 ms/angle.)
                     for (int j4 = 0; j4 < n_own; j4 += 4) {                                    // wave-uniform
                         const uint4 e = *(const uint4 *)(te + j4);                           // broadcast reads
                         const float4 wa = tw[j4], wb = tw[j4 + 1], wc = tw[j4 + 2], wd = tw[j4 + 3];
