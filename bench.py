@@ -405,6 +405,10 @@ def make_roofline(name, ms_per_step, launches_per_step, alg_bytes_per_pass, key,
     util = {}
     if pmc is not None:
         util["hbm"] = (pmc / t / 1e9, HBM_PEAK_GBS, "GB/s")
+    if write_bytes is not None and name.startswith("k_fwd"):
+        # a unit of its own: no-return float atomics execute at the memory side at ~1.3 TB/s of added bytes whatever their locality or
+        # scope (MI355X_MICROARCH.md; tools/gatomic_scope_bench.hip) -- the forward kernels cannot finish before their atomics have
+        util["atomics"] = (write_bytes / t / 1e9, ATOMIC_PEAK_GBS, "GB/s of float atomics")
     if sq is not None:
         # unit-busy cycles counted by the SQ for this launch (MI355X_MICROARCH: SQ_LDS_IDX_ACTIVE = all LDS-array cycles;
         # SQ_ACTIVE_INST_VALU counts quad-cycles of VALU execution per SIMD) against the cycles the chip has in the live time
@@ -419,7 +423,7 @@ def make_roofline(name, ms_per_step, launches_per_step, alg_bytes_per_pass, key,
         return r
     # `valu` is AMD's VALUBusy: a wave64 VALU instruction is counted as one quad-cycle of its SIMD although the SIMD retires the
     # simple integer ones faster (tools/issue_bench.hip: v_add_u32 one per 2 clk, v_fma_f32 one per 2.65), so a kernel made of those
-    # can read slightly above 1 (the tilted adjoint reads 1.04); `lds` and `hbm` are capped by 1.
+    # can read slightly above 1 (the tilted adjoint reads 1.04); `lds`, `hbm` and `atomics` are capped by 1.
     bound = max(util, key=lambda k: util[k][0] / util[k][1])
     ach, peak, unit = util[bound]
     r.update({"bound": bound, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": unit, "frac": round(ach / peak, 4),

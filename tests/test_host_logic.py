@@ -385,6 +385,7 @@ def test_bench_launcher_and_roofline_logic_without_a_gpu(tmp_path, monkeypatch):
     assert abs(r["atomics"]["amplification_vs_sinogram"] - 2.6e11 / (4.0 * 1024 ** 3)) < 0.1
     # LDS-array cycles 2.4e11 / 0.5 s = 480 G/s of the 614.4 G/s (256 CUs x 2.4 GHz) = 0.78; VALU 4 x 1.5e11 / 0.5 = 1200 of 2457.6 = 0.49
     assert r["bound"] == "lds" and 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - 2.4e11 / 0.5 / 1e9 / 614.4) < 1e-3
+    assert abs(r["utilisation"]["atomics"]["frac"] - 0.4) < 1e-3                       # the memory-side atomic unit is one of the candidates
     assert abs(r["utilisation"]["valu"]["frac"] - 4 * 1.5e11 / 0.5 / 1e9 / 2457.6) < 1e-3 and r["utilisation"]["hbm"]["frac"] < 0.2
     assert r["hbm_algorithmic"]["frac_of_hbm_peak"] > 1.0 and r["traffic"] == 4.0e11          # kept, labelled, not the roofline
     assert r["instruction_rates"]["lds_GBps"] > 0

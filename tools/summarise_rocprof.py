@@ -22,7 +22,7 @@ def _src_hash():
 
 
 ALIAS = {"k_adj_gather_flat<3>": "k_adj_gather_flat", "k_adj_gather_flat<6>": "k_adj_gather_flat", "k_tile_flat<true>": "k_fwd_tile_flat", "k_fwd_flat_z<2>": "k_fwd_tile_flat", "k_fwd_flat_z<1>": "k_fwd_tile_flat", "k_fwd_flat_z<2, 16>": "k_fwd_tile_flat", "k_fwd_flat_z<1, 16>": "k_fwd_tile_flat",
-         "k_fwd_flat_z<1, 32>": "k_fwd_tile_flat", "k_tile_flat<false>": "k_adj_tile_flat", "k_tile<true>": "k_fwd_tile",
+         "k_fwd_flat_z<1, 32>": "k_fwd_tile_flat", "k_fwd_flat_tab": "k_fwd_tile_flat", "k_tile_flat<false>": "k_adj_tile_flat", "k_tile<true>": "k_fwd_tile",
          "k_tile<false>": "k_adj_tile", "k_proj_grad<true>": "k_cost_grad(v1)", "k_proj_grad<false>": "k_proj_grad(v1)",
          "k_proj_grad_v2<true>": "k_cost_grad(v2)", "k_proj_grad_v2<false>": "k_proj_grad(v2)",
          "k_proj_grad_v3<true>": "k_cost_grad(v3)", "k_proj_grad_v3<false>": "k_proj_grad(v3)"}
