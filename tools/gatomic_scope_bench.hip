@@ -22,6 +22,7 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float *tab, unsigne
         h = h * 1664525u + 1013904223u;
         unsigned row = (h >> 8) & n_rows_mask;
         if (xcd_local) row = (row & ~7u) | xcd;
+        if (MODE == 8 || MODE == 9) row &= ~1u;             // 512 B = two rows of the table
         float *p = tab + (size_t)row * 64 + lane;
         const float v = 1.0f;
         if (MODE == 0) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -31,8 +32,11 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float *tab, unsigne
         else if (MODE == 4) *p = v + (float)it;                              // plain store
         else if (MODE == 5) { float o = *p; *p = o + v; }                    // plain read-modify-write (NOT safe with several adders per row)
         else if (MODE == 6) acc += *p;                                        // plain load
+        else if (MODE == 7) acc += __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // RETURNING atomic (old value used)
+        else if (MODE == 8) __hip_atomic_fetch_add((unsigned long long *)(tab + (size_t)row * 64) + lane, 0x0000000100000001ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // u64: 8 B per lane, 512 B per wave-instruction (two rows)
+        else if (MODE == 9) __hip_atomic_fetch_add((double *)(tab + (size_t)row * 64) + lane, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (MODE == 6) sink[wid * 64 + lane] = acc;
+    if (MODE == 6 || MODE == 7) sink[wid * 64 + lane] = acc;
 }
 
 template <int MODE> void run(const char *name, size_t table_bytes, int xcd_local, int check)
@@ -55,8 +59,9 @@ template <int MODE> void run(const char *name, size_t table_bytes, int xcd_local
     (void)hipEventSynchronize(e1);
     float ms;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    const double bytes = (double)blocks * 4 * N_IT * 256;
+    const double bytes = (double)blocks * 4 * N_IT * ((MODE == 8 || MODE == 9) ? 512 : 256);
     double total = -1;
+    if (MODE == 8 || MODE == 9) check = 0;
     if (check) {                 // no add may be lost: the table must sum to the number of adds
         float *h = (float *)malloc(table_bytes);
         (void)hipMemcpy(h, tab, table_bytes, hipMemcpyDeviceToHost);
@@ -80,6 +85,10 @@ int main()
             run<2>("atomic add f32, wavefront scope", b, loc, 1);
             run<3>("atomic add f32, system scope", b, loc, 1);
         }
+        run<7>("atomic add f32, agent, RETURNING", b, 0, 1);
+        run<7>("atomic add f32, agent, RETURNING", b, 1, 1);
+        run<8>("atomic add u64 (8 B per lane)", b, 0, 0);
+        run<9>("atomic add f64 (8 B per lane)", b, 0, 0);
         run<4>("plain store", b, 0, 0);
         run<5>("plain load + add + store", b, 0, 0);
         run<6>("plain load", b, 0, 0);
