@@ -463,8 +463,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
 {
     __shared__ __attribute__((aligned(16))) float img[ALX * ALY * FLZ * 2];                  // [x][y][plane][image]
     __shared__ float4 tab_w[FZ_WAVES * FT2_TAB_ALLOC];
-    __shared__ __attribute__((aligned(16))) unsigned tab_e[FZ_WAVES * FT2_TAB_ALLOC];
-    static_assert(sizeof(float) * ALX * ALY * FLZ * 2 + 20 * FZ_WAVES * FT2_TAB_ALLOC <= 160 * 1024, "LDS");
+    static_assert(sizeof(float) * ALX * ALY * FLZ * 2 + 16 * FZ_WAVES * FT2_TAB_ALLOC <= 160 * 1024, "LDS");
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int z0 = -1 + (int)blockIdx.x * (2 * FTZ), y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + ((int)blockIdx.z + tile_x0) * ATX;
@@ -489,7 +488,6 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
     const float two_m32 = 2.3283064365386963e-10f;
     const unsigned lane8 = (unsigned)min(lane, FLZ - 1) * 8u;
     float4 *const tw = tab_w + wv * FT2_TAB_ALLOC;
-    unsigned *const te = tab_e + wv * FT2_TAB_ALLOC;
     const lds_cfloat *const img_l = (const lds_cfloat *)img;            // explicit LDS pointer (address space 3): ds_read, not flat loads
 
     for (int ip = wv; ip < n_proj; ip += FZ_WAVES) {               // one wave owns a whole (tile stack, projection)
@@ -552,28 +550,35 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
                     const int n_own = (int)__builtin_popcountll(om);
                     const int first = (int)__builtin_ctzll(om);
                     const unsigned slot = (unsigned)(lane - first);
-                    if (slot < (unsigned)(n_own + 3)) {                                      // ONE masked pair of writes: the three lanes behind the owners write zeros
-                        const bool mine = slot < (unsigned)n_own;
-                        tw[slot] = make_float4(mine ? t_w00 : 0.f, mine ? t_w01 : 0.f, mine ? t_w10 : 0.f, mine ? t_w11 : 0.f);
-                        te[slot] = mine ? t_e : 0u;
-                    }
-                    // groups of four entries: 1 + 4 broadcast ds_read_b128 (addresses, weights), then per entry 4 ds_read_b64 + 4 packed FMAs.
-                    // (Measured and dropped in round 3: fetching the next group's table words before this group's data reads are consumed
-                    // -- with copies 37, with two named register sets 63 VALU per 8 entries and a branch: 0.375 against 0.356 ms/angle.)
-                    for (int j4 = 0; j4 < n_own; j4 += 4) {                                    // wave-uniform
-                        const uint4 e = *(const uint4 *)(te + j4);                           // broadcast reads
-                        const float4 wa = tw[j4], wb = tw[j4 + 1], wc = tw[j4 + 2], wd = tw[j4 + 3];
-#define FT2_ENTRY(E, W)                                                                                                    \
+                    if (slot < (unsigned)n_own) tw[slot] = make_float4(t_w00, t_w01, t_w10, t_w11);      // owners only: no padding entries (see the loops)
+                    // The cell ADDRESS of an entry is broadcast with one v_readlane (lanes that own nothing carry address 0), the four weights come
+                    // from the wave's LDS table (broadcast ds_read_b128): the data reads of a group do not wait for an LDS round trip of the table
+                    // -- they are issued beside the weight reads, which are needed only at the FMAs.  4 + 8 LDS clk per entry.
+                    const int c_e = (int)select_lanes_u(t_e, om);
+                    // Entries in groups of four (four sets of reads in flight per wave), the 0 .. 3 left over one by one: no zero-padding entries.
+                    // Variants measured in round 3 on a dense 1024^3 volume, ms per angle (profiles/round3_fwd_tab_variants.md): addresses in the
+                    // LDS table too, zero-padded groups of four 0.352; this form with zero-padded groups of four 0.345, of eight 0.388, of
+                    // two 0.336, one by one 0.335; groups of four + tail (this code) 0.329; eight + four + tail 0.333; the next group's table
+                    // words fetched ahead 0.375; hand software-pipelined with two register sets 0.355.  Round 2's kernel: 0.434.
+#define FT2_ENTRY(J, W)                                                                                                    \
                         {                                                                                                   \
                             /* explicit LDS pointer; volatile keeps four ds_read_b64 (2 LDS clk each): merged into ds_read2st64_b64 */ \
                             /* they cost 8 clk per pair (MI355X_MICROARCH.md, LDS table)                                           */ \
                             typedef __attribute__((address_space(3))) const volatile f32x2 lds_v2;                          \
-                            const __attribute__((address_space(3))) char *q_ = (const __attribute__((address_space(3))) char *)img_l + ((E) + lane8); \
+                            const unsigned e_ = (unsigned)__builtin_amdgcn_readlane(c_e, first + j4 + (J));                 \
+                            const __attribute__((address_space(3))) char *q_ = (const __attribute__((address_space(3))) char *)img_l + (e_ + lane8); \
                             const f32x2 v00 = *(lds_v2 *)(q_), v01 = *(lds_v2 *)(q_ + FLZ * 8);                             \
                             const f32x2 v10 = *(lds_v2 *)(q_ + ALY * FLZ * 8), v11 = *(lds_v2 *)(q_ + (ALY + 1) * FLZ * 8); \
                             Pa += (W).x * v00; Pb += (W).y * v01; Pa += (W).z * v10; Pb += (W).w * v11;                     \
                         }
-                        FT2_ENTRY(e.x, wa) FT2_ENTRY(e.y, wb) FT2_ENTRY(e.z, wc) FT2_ENTRY(e.w, wd)
+                    int j4 = 0;
+                    for (; j4 + 4 <= n_own; j4 += 4) {                                         // wave-uniform; four entries in flight, no padding
+                        const float4 wa = tw[j4], wb = tw[j4 + 1], wc = tw[j4 + 2], wd = tw[j4 + 3];
+                        FT2_ENTRY(0, wa) FT2_ENTRY(1, wb) FT2_ENTRY(2, wc) FT2_ENTRY(3, wd)
+                    }
+                    for (; j4 < n_own; j4 += 1) {                                              // the 0 .. 3 entries left
+                        const float4 wa = tw[j4];
+                        FT2_ENTRY(0, wa)
 #undef FT2_ENTRY
                     }
                 }
@@ -587,7 +592,15 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
                     // the float atomics are this kernel's tightest bound (0.83 of the memory side's 1.3 TB/s): a row that crossed only
                     // zero voxels of a live tile adds nothing -- skip the whole 256-B instruction (wave-uniform test)
                     if (__builtin_amdgcn_ballot_w64(ray_ok[k] && val != 0.f) == 0) continue;
+#ifdef TOMO_ABLATE_FWD_ATOMICS          // measurement builds only (tools/gpu_r3l.sh): what the kernel costs without its atomics / with plain stores
+#if TOMO_ABLATE_FWD_ATOMICS == 2
+                    if (ray_ok[k]) pr[k * FTZ] = val;
+#else
+                    asm volatile("" :: "v"(val));
+#endif
+#else
                     if (ray_ok[k]) atomicAdd(pr + k * FTZ, val);
+#endif
                 }
             }
         }
