@@ -569,7 +569,13 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
                             const __attribute__((address_space(3))) char *q_ = (const __attribute__((address_space(3))) char *)img_l + (e_ + lane8); \
                             const f32x2 v00 = *(lds_v2 *)(q_), v01 = *(lds_v2 *)(q_ + FLZ * 8);                             \
                             const f32x2 v10 = *(lds_v2 *)(q_ + ALY * FLZ * 8), v11 = *(lds_v2 *)(q_ + (ALY + 1) * FLZ * 8); \
-                            Pa += (W).x * v00; Pb += (W).y * v01; Pa += (W).z * v10; Pb += (W).w * v11;                     \
+                            /* weight = one half of an aligned register pair, broadcast to both images by op_sel (the compiler   */ \
+                            /* copies W.w to a fresh register first: one v_mov per entry)                                          */ \
+                            const f32x2 w01_ = {(W).x, (W).y}, w23_ = {(W).z, (W).w};                                       \
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(Pa) : "v"(w01_), "v"(v00));          \
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(Pb) : "v"(w01_), "v"(v01));             \
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(Pa) : "v"(w23_), "v"(v10));          \
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(Pb) : "v"(w23_), "v"(v11));             \
                         }
                     int j4 = 0;
                     for (; j4 + 4 <= n_own; j4 += 4) {                                         // wave-uniform; four entries in flight, no padding
@@ -587,7 +593,8 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     if (!zuse[k]) continue;
-                    const float Sp1 = __shfl_down(S[k], 1, 64);                // plane lane+1
+                    // plane lane + 1 by a DPP wave shift (a VALU move; __shfl_down is a ds_bpermute_b32: an LDS round trip per row and image)
+                    const float Sp1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(S[k]), 0x130, 0xf, 0xf, true));
                     const float val = wfz * S[k] + wcz * Sp1;
                     // the float atomics are this kernel's tightest bound (0.83 of the memory side's 1.3 TB/s): a row that crossed only
                     // zero voxels of a live tile adds nothing -- skip the whole 256-B instruction (wave-uniform test)

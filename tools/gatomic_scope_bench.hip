@@ -35,6 +35,15 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float *tab, unsigne
         else if (MODE == 7) acc += __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // RETURNING atomic (old value used)
         else if (MODE == 8) __hip_atomic_fetch_add((unsigned long long *)(tab + (size_t)row * 64) + lane, 0x0000000100000001ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // u64: 8 B per lane, 512 B per wave-instruction (two rows)
         else if (MODE == 9) __hip_atomic_fetch_add((double *)(tab + (size_t)row * 64) + lane, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (MODE >= 10) {
+            // ALIGNMENT of a row instruction (the flat forward adds 63 consecutive floats at an arbitrary float offset): 10 = 63 lanes at a
+            // pseudo-random float offset, 11 = 63 lanes aligned to 256 B, 12 = 64 lanes offset by 32 floats (128-B aligned), 13 = 64 lanes
+            // offset by 16 floats (64-B aligned), 14 = 64 lanes offset by 1 float, 15 = 32 lanes aligned to 128 B
+            const unsigned off = MODE == 10 ? ((h >> 2) & 63u) : MODE == 12 ? 32u : MODE == 13 ? 16u : MODE == 14 ? 1u : 0u;
+            float *q = tab + (size_t)(row & (n_rows_mask >> 1)) * 64 + off + lane;          // the offset row stays inside the table
+            const int n_act = (MODE == 10 || MODE == 11) ? 63 : MODE == 15 ? 32 : 64;
+            if (lane < n_act) __hip_atomic_fetch_add(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (MODE == 6 || MODE == 7) sink[wid * 64 + lane] = acc;
 }
@@ -59,7 +68,7 @@ template <int MODE> void run(const char *name, size_t table_bytes, int xcd_local
     (void)hipEventSynchronize(e1);
     float ms;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    const double bytes = (double)blocks * 4 * N_IT * ((MODE == 8 || MODE == 9) ? 512 : 256);
+    const double bytes = (double)blocks * 4 * N_IT * ((MODE == 8 || MODE == 9) ? 512 : (MODE == 10 || MODE == 11) ? 252 : MODE == 15 ? 128 : 256);
     double total = -1;
     if (MODE == 8 || MODE == 9) check = 0;
     if (check) {                 // no add may be lost: the table must sum to the number of adds
@@ -89,6 +98,12 @@ int main()
         run<7>("atomic add f32, agent, RETURNING", b, 1, 1);
         run<8>("atomic add u64 (8 B per lane)", b, 0, 0);
         run<9>("atomic add f64 (8 B per lane)", b, 0, 0);
+        run<11>("atomic f32, 63 lanes, 256-B aligned", b, 0, 1);
+        run<10>("atomic f32, 63 lanes, any float offset", b, 0, 1);
+        run<12>("atomic f32, 64 lanes, +128 B", b, 0, 1);
+        run<13>("atomic f32, 64 lanes, +64 B", b, 0, 1);
+        run<14>("atomic f32, 64 lanes, +4 B", b, 0, 1);
+        run<15>("atomic f32, 32 lanes, 128-B aligned", b, 0, 1);
         run<4>("plain store", b, 0, 0);
         run<5>("plain load + add + store", b, 0, 0);
         run<6>("plain load", b, 0, 0);
