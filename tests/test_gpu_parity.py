@@ -346,13 +346,14 @@ def test_untilted_poses_take_the_flat_tile_kernels(PM, orc, shape, ndet):
 
 
 @pytest.mark.parametrize("shape,ndet,step", [((40, 36, 130), (44, 150), 1.0), ((70, 33, 64), (70, 64), 1.0), ((33, 20, 70), (30, 80), 1.0),
-                                             ((40, 36, 130), (44, 150), 0.5), ((20, 24, 200), (20, 190), 0.75)])
+                                             ((40, 36, 130), (44, 150), 0.5), ((20, 24, 200), (20, 190), 0.75), ((24, 20, 300), (24, 310), 1.0)])
 def test_flat_forward_kernel_variants(PM, orc, shape, ndet, step):
     """The variants of the flat forward -- the round-2 kernel (entries broadcast with v_readlane, option fwd_flat_tab = 0), the round-3
     kernel (sample table in LDS, the two images interleaved per plane: fwd_flat_tab = 1) and the 32 x 16-footprint measurement variant
     (fwd_flat_wide, DESIGN.md section 4 "forward write amplification") -- compute the same projections as each other and as the
     oracle: volumes whose x extent is not a multiple of 32, exactly degenerate angles, translations, COR shifts, and steps below a
-    voxel (rows with more samples in a tile than one pass of the table holds)."""
+    voxel (rows with more samples in a tile than one pass of the table holds); z extents of one to three of the round-3 kernel's
+    128-plane work-groups with fractional z translations (the ray between two work-groups receives a part from each)."""
     rng = np.random.default_rng(7)
     n_proj = 5
     phi = np.array([0.0, 0.37, np.pi / 2, 2.2, np.pi])

@@ -451,10 +451,19 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
 //   * the two z-stacked images are interleaved per PLANE, [x][y][64 planes][image]: the values a lane needs from both images for a
 //     corner are one aligned 8-byte word -> 4 ds_read_b64 per entry at immediate offsets of ONE address (y + 1: +512 B, x + 1:
 //     +8704 B), 2 LDS clk each, the register pair (image 0, image 1) feeds v_pk_fma_f32 directly;
-//   * entries are fetched four at a time with broadcast ds_read_b128 (1 for the 4 addresses + 4 for the weights = 5 LDS clk per
-//     entry), their weights arrive in VGPRs: 4 v_pk_fma_f32 + 1 v_add_u32 per entry and lane, no v_readlane.
-// LDS 13 clk and VALU ~6 clk per entry and CU against 17.6 / ~12 (+ set-up) of k_fwd_flat_z<2>.
+//   * an entry's four weights come back from a wave-private LDS table by broadcast ds_read_b128 (4 LDS clk), its cell address by one
+//     v_readlane: 4 v_pk_fma_f32 + 1 v_add_u32 + 1 v_readlane per entry.
+// LDS 12 clk and VALU ~6.3 instructions per entry against 17.6 / ~12 (+ set-up) of k_fwd_flat_z<2>.
 // Same sums as k_fwd_flat_z<2>, in the same order per row (entries ascending, four accumulator pairs -> two).
+//   * NO HALO PLANE (second half of round 3): an image is 64 owned planes, a work-group owns planes [128 b, 128 b + 128) and all 64 lanes
+//     of both images carry a ray.  The plane above a lane's own (the z-lerp's upper neighbour) is the next lane's sum (DPP shift), for
+//     lane 63 of image 0 it is image 1's lane 0, for lane 63 of image 1 it belongs to the NEXT work-group in z -- which adds its
+//     w_c * S[0] to that ray itself (one single-lane atomic per row, only when the projection's z fraction w_c is not 0: the nominal
+//     geometry has w_c = 0).  Why: at 1024 angles per launch (a 4.3 GB sinogram) the memory-side float atomics bound this kernel --
+//     0.327 ms/angle with them, 0.273 without (profiles/round3_fwd_tab_variants.md) -- and they are priced per 64-B unit touched
+//     (tools/gatomic_scope_bench.hip: a 63-float row at an arbitrary float offset runs at 1.07 TB/s, 64-B aligned at 1.29).  With
+//     128-plane work-groups a row instruction is 64 floats starting at ray 128 b + 64 k - floor(p0z): aligned whenever floor(p0z) is a
+//     multiple of 16 (0 in the nominal geometry) -- 4 units instead of 4.9 -- and a 1024-plane volume takes 8 work-groups in z, not 9.
 // ------------------------------------------------------------------------------------------------
 #define FT2_TAB 32
 #define FT2_TAB_ALLOC (FT2_TAB + 4)      // + 3 zero entries behind the owners (the loop runs in unmasked groups of four)
@@ -466,14 +475,19 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
     static_assert(sizeof(float) * ALX * ALY * FLZ * 2 + 16 * FZ_WAVES * FT2_TAB_ALLOC <= 160 * 1024, "LDS");
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int z0 = -1 + (int)blockIdx.x * (2 * FTZ), y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + ((int)blockIdx.z + tile_x0) * ATX;
+    // grid = (z work-groups, y tiles, x tiles), the z index ROTATED by the y tile index.  Work-groups are dealt to the 8 XCDs round-robin by
+    // linear id: with the plain z index fastest a 1024-plane volume (8 work-groups in z) pins each z range to ONE XCD, and the mostly
+    // empty top and bottom ranges of a phantom idle two XCDs (measured on the Shepp-Logan volume: 0.183 ms/angle against 0.137 with the y
+    // index fastest); with y fastest the work-groups in flight add to different sinogram rows (dense: 0.270 against 0.264 ms/angle with
+    // z fastest, whose concurrent work-groups add to neighbouring 512-B pieces of the same rows).  Rotated: both.
+    const int z0 = (int)((blockIdx.x + blockIdx.y) % gridDim.x) * (2 * FLZ), y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + ((int)blockIdx.z + tile_x0) * ATX;
     bool live[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         bool any_nz = false;
         for (int e = threadIdx.x; e < ALX * ALY * FLZ; e += FZ_WAVES * 64) {
             const int lz = e % FLZ, t2 = e / FLZ, ly = t2 % ALY, lx = t2 / ALY;
-            const int gx = x0 + lx, gy = y0 + ly, gz = z0 + k * FTZ + lz;
+            const int gx = x0 + lx, gy = y0 + ly, gz = z0 + k * FLZ + lz;
             float v = 0.f;
             if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz) v = vol[((size_t)gx * g.ny + gy) * g.nz + gz];
             img[e * 2 + k] = v;
@@ -486,7 +500,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
     const int64_t orgx = (int64_t)x0 << 32, orgy = (int64_t)y0 << 32;
     const size_t n_det = (size_t)g.ndx * g.ndz;
     const float two_m32 = 2.3283064365386963e-10f;
-    const unsigned lane8 = (unsigned)min(lane, FLZ - 1) * 8u;
+    const unsigned lane8 = (unsigned)lane * 8u;
     float4 *const tw = tab_w + wv * FT2_TAB_ALLOC;
     const lds_cfloat *const img_l = (const lds_cfloat *)img;            // explicit LDS pointer (address space 3): ds_read, not flat loads
 
@@ -495,15 +509,18 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
         const int p0z_i = (int)(c.fp0[2] >> 32);
         const float wcz = (float)(unsigned)c.fp0[2] * two_m32, wfz = 1.f - wcz;
         bool zuse[2], ray_ok[2];
-        const int iz0 = z0 - p0z_i + lane;                             // this lane's ray in the lower tile; + FTZ in the upper
+        const int izb = z0 - p0z_i;                                    // the ray whose lower plane is image 0's plane 0
+        const int iz0 = izb + lane;                                    // this lane's ray in image 0; + FLZ in image 1
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int izoff = z0 + k * FTZ - p0z_i;
-            zuse[k] = live[k] && !(izoff + FTZ <= 0 || izoff >= g.ndz);
-            const int iz = iz0 + k * FTZ;
-            ray_ok[k] = zuse[k] && lane < FTZ && iz >= 0 && iz < g.ndz;
+            const int izoff = izb + k * FLZ;
+            zuse[k] = live[k] && !(izoff + FLZ <= 0 || izoff >= g.ndz);
+            const int iz = iz0 + k * FLZ;
+            ray_ok[k] = zuse[k] && iz >= 0 && iz < g.ndz;
         }
-        if (!(zuse[0] || zuse[1])) continue;
+        // the ray BELOW image 0's first (its upper plane is this work-group's plane 0, its lower one the previous work-group's last)
+        const bool low_ray = live[0] && wcz != 0.f && izb - 1 >= 0 && izb - 1 < g.ndz;
+        if (!(zuse[0] || zuse[1] || low_ray)) continue;
         const float qx = bcx - (float)c.p0[0], qy = bcy - (float)c.p0[1];
         const float m00 = (float)c.minv[0][0], m01 = (float)c.minv[0][1];
         const float ixc = m00 * qx + m01 * qy;
@@ -590,23 +607,30 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
                 }
                 const f32x2 Pt = Pa + Pb;
                 const float S[2] = {Pt.x, Pt.y};
+                if (low_ray) {                                                 // wave-uniform; never taken in the nominal geometry (w_c = 0)
+                    const float vlo = wcz * S[0];
+                    if (lane == 0 && vlo != 0.f) atomicAdd(pr - 1, vlo);       // pr points at this lane's ray of image 0: lane 0's is ray izb
+                }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     if (!zuse[k]) continue;
-                    // plane lane + 1 by a DPP wave shift (a VALU move; __shfl_down is a ds_bpermute_b32: an LDS round trip per row and image)
-                    const float Sp1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(S[k]), 0x130, 0xf, 0xf, true));
+                    // plane lane + 1 by a DPP wave shift (a VALU move; __shfl_down is a ds_bpermute_b32: an LDS round trip per row and image);
+                    // lane 63 receives 0 (bound_ctrl) -- image 0's lane 63 then takes image 1's plane 0, image 1's lane 63 keeps 0: that
+                    // plane belongs to the next work-group in z (see low_ray there)
+                    float Sp1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(S[k]), 0x130, 0xf, 0xf, true));
+                    if (k == 0) Sp1 = lane == 63 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S[1]), 0)) : Sp1;
                     const float val = wfz * S[k] + wcz * Sp1;
-                    // the float atomics are this kernel's tightest bound (0.83 of the memory side's 1.3 TB/s): a row that crossed only
+                    // the float atomics are this kernel's tightest bound (see the header): a row that crossed only
                     // zero voxels of a live tile adds nothing -- skip the whole 256-B instruction (wave-uniform test)
                     if (__builtin_amdgcn_ballot_w64(ray_ok[k] && val != 0.f) == 0) continue;
 #ifdef TOMO_ABLATE_FWD_ATOMICS          // measurement builds only (tools/gpu_r3l.sh): what the kernel costs without its atomics / with plain stores
 #if TOMO_ABLATE_FWD_ATOMICS == 2
-                    if (ray_ok[k]) pr[k * FTZ] = val;
+                    if (ray_ok[k]) pr[k * FLZ] = val;
 #else
                     asm volatile("" :: "v"(val));
 #endif
 #else
-                    if (ray_ok[k]) atomicAdd(pr + k * FTZ, val);
+                    if (ray_ok[k]) atomicAdd(pr + k * FLZ, val);
 #endif
                 }
             }

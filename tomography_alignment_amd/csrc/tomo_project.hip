@@ -243,7 +243,7 @@ static int forward_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
             TOMO_LAUNCH(ctx, "k_fwd_tile_flat", (k_fwd_flat_z<1, 32>), dim3(fg.x, fg.y, (g.nx + 1 + 31) / 32), dim3(FZ_WAVES * 64), 0, d_c, n_flat,
                         d_proj, d_vol, g, 0);
         else if (fg.x >= 2 && ctx->fwd_flat_ztiles >= 2 && ctx->fwd_flat_tab)      // round 3: LDS sample table + image pairs
-            TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_fwd_flat_tab, dim3((fg.x + 1) / 2, fg.y, fg.z), dim3(FZ_WAVES * 64), 0, d_c, n_flat,
+            TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_fwd_flat_tab, dim3((g.nz + 2 * FLZ - 1) / (2 * FLZ), fg.y, fg.z), dim3(FZ_WAVES * 64), 0, d_c, n_flat,
                         d_proj, d_vol, g, xt0);
         else if (fg.x >= 2 && ctx->fwd_flat_ztiles >= 2)         // two z-adjacent tiles per work-group share the per-row set-up
             TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_fwd_flat_z<2>, dim3((fg.x + 1) / 2, fg.y, fg.z), dim3(FZ_WAVES * 64), 0, d_c, n_flat,
