@@ -380,6 +380,16 @@ def test_flat_forward_kernel_variants(PM, orc, shape, ndet, step):
     assert ctx.profile_get("k_fwd_tile_flat")[0] == 3 and ctx.profile_get("k_fwd_tile")[0] == 0
     assert rel_max(res[0], want) < TOL and rel_max(res[1], want) < TOL and rel_max(f_wide, want) < TOL
     assert rel_max(res[1], res[0]) < 2e-6 and rel_max(f_wide, res[0]) < 2e-6
+    # all-zero images beside non-zero ones (the kernels skip them): the ray between two images / two work-groups of the round-3 kernel
+    # must still receive the part of the one that is not zero (planes 0..63 empty, 64..99 full, 100..127 empty, 128.. full)
+    xs = x.copy()
+    xs[:, :, :64] = 0
+    xs[:, :, 100:128] = 0
+    want_s = orc.forward(og, xs, phi=phi, xyz_shift=xyz).ravel()
+    for tab in (0, 1):
+        ctx.set_option("fwd_flat_tab", tab)
+        assert rel_max(A.dot(xs.ravel()), want_s) < TOL, tab
+    ctx.set_option("fwd_flat_tab", TAB_DEFAULT)
 
 
 def test_mixed_tilted_and_untilted_call(PM, orc):

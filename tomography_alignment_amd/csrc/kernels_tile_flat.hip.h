@@ -514,7 +514,8 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int izoff = izb + k * FLZ;
-            zuse[k] = live[k] && !(izoff + FLZ <= 0 || izoff >= g.ndz);
+            // image 0's last ray has image 1's plane 0 above it: image 0 is written whenever EITHER image holds a non-zero voxel
+            zuse[k] = (live[k] || (k == 0 && live[1])) && !(izoff + FLZ <= 0 || izoff >= g.ndz);
             const int iz = iz0 + k * FLZ;
             ray_ok[k] = zuse[k] && iz >= 0 && iz < g.ndz;
         }
@@ -620,17 +621,18 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
                     float Sp1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(S[k]), 0x130, 0xf, 0xf, true));
                     if (k == 0) Sp1 = lane == 63 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S[1]), 0)) : Sp1;
                     const float val = wfz * S[k] + wcz * Sp1;
-                    // the float atomics are this kernel's tightest bound (see the header): a row that crossed only
-                    // zero voxels of a live tile adds nothing -- skip the whole 256-B instruction (wave-uniform test)
-                    if (__builtin_amdgcn_ballot_w64(ray_ok[k] && val != 0.f) == 0) continue;
+                    // the float atomics are this kernel's tightest bound (see the header) and are priced per 64-B unit touched: lanes whose
+                    // value is 0 (rays that crossed only zero voxels of a live tile) do not take part, a row of zeros issues nothing
+                    const bool add = ray_ok[k] && val != 0.f;
+                    if (__builtin_amdgcn_ballot_w64(add) == 0) continue;
 #ifdef TOMO_ABLATE_FWD_ATOMICS          // measurement builds only (tools/gpu_r3l.sh): what the kernel costs without its atomics / with plain stores
 #if TOMO_ABLATE_FWD_ATOMICS == 2
-                    if (ray_ok[k]) pr[k * FLZ] = val;
+                    if (add) pr[k * FLZ] = val;
 #else
                     asm volatile("" :: "v"(val));
 #endif
 #else
-                    if (ray_ok[k]) atomicAdd(pr + k * FLZ, val);
+                    if (add) atomicAdd(pr + k * FLZ, val);
 #endif
                 }
             }
