@@ -135,6 +135,14 @@ __device__ __forceinline__ int64_t add64_vs(int64_t p, int64_t step)
     return p;
 }
 
+// the same sum into a NEW register pair (where the first operand is needed again: no copy in front of the in-place form)
+__device__ __forceinline__ int64_t sum64_vs(int64_t p, int64_t step)
+{
+    int64_t r;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(p), "s"(step));
+    return r;
+}
+
 // FWD = true : the LDS image holds the volume tile (+1 high-side halo, zeros outside the volume); owned samples are
 //              interpolated from it with ds_read and each (tile, projection, detector row) adds its partial ray sums to
 //              proj with one 256-B global float atomic per wave -- the volume is read from HBM once per CALL, not per angle.

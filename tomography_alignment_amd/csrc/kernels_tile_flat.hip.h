@@ -465,6 +465,9 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
 //     128-plane work-groups a row instruction is 64 floats starting at ray 128 b + 64 k - floor(p0z): aligned whenever floor(p0z) is a
 //     multiple of 16 (0 in the nominal geometry) -- 4 units instead of 4.9 -- and a 1024-plane volume takes 8 work-groups in z, not 9.
 // ------------------------------------------------------------------------------------------------
+#ifndef TOMO_FWD_TAB_W
+#define TOMO_FWD_TAB_W 1         // where an entry's weights come from: 1 = the wave's LDS table (shipped); 0 / 2 = measurement variants (see the loop)
+#endif
 #define FT2_TAB 32
 #define FT2_TAB_ALLOC (FT2_TAB + 4)      // + 3 zero entries behind the owners (the loop runs in unmasked groups of four)
 __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
@@ -554,10 +557,10 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
                 for (int jc = jlo; jc < jhi; jc += FT2_TAB) {
                     int64_t ux = rbx + (int64_t)jc * k_fdx, uy = rby + (int64_t)jc * k_fdy;
                     asm volatile("" : "+s"(ux), "+s"(uy));
-                    const int64_t px = add64_vs(ldx, ux), py = add64_vs(ldy, uy);
+                    const int64_t px = sum64_vs(ldx, ux), py = sum64_vs(ldy, uy);
                     const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32);
                     const unsigned long long om = __builtin_amdgcn_ballot_w64((lx | ly) < (unsigned)ATX) &
-                                                  __builtin_amdgcn_ballot_w64(jc + lane < min(jhi, jc + FT2_TAB));
+                                                  __builtin_amdgcn_ballot_w64(lane < min(jhi - jc, FT2_TAB));
                     if (om == 0) continue;
                     const unsigned t_e = (__umul24(lx, ALY * FLZ * 2) + __umul24(ly, FLZ * 2)) * 4u;      // byte offset of cell (lx, ly), plane 0, image 0
                     const float wx = (float)(unsigned)px * two_m32, wy = (float)(unsigned)py * two_m32;
@@ -568,11 +571,15 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
                     const int n_own = (int)__builtin_popcountll(om);
                     const int first = (int)__builtin_ctzll(om);
                     const unsigned slot = (unsigned)(lane - first);
+#if TOMO_FWD_TAB_W == 1
                     if (slot < (unsigned)n_own) tw[slot] = make_float4(t_w00, t_w01, t_w10, t_w11);      // owners only: no padding entries (see the loops)
+#elif TOMO_FWD_TAB_W == 2
+                    if (slot < (unsigned)n_own) ((float2 *)tw)[slot] = make_float2(t_w10, t_w11);
+#endif
                     // The cell ADDRESS of an entry is broadcast with one v_readlane (lanes that own nothing carry address 0), the four weights come
                     // from the wave's LDS table (broadcast ds_read_b128): the data reads of a group do not wait for an LDS round trip of the table
                     // -- they are issued beside the weight reads, which are needed only at the FMAs.  4 + 8 LDS clk per entry.
-                    const int c_e = (int)select_lanes_u(t_e, om);
+                    const int c_e = (int)t_e;                       // only the owners' lanes first .. first + n_own - 1 are ever read
                     // Entries in groups of four (four sets of reads in flight per wave), the 0 .. 3 left over one by one: no zero-padding entries.
                     // Variants measured in round 3 on a dense 1024^3 volume, ms per angle (profiles/round3_fwd_tab_variants.md): addresses in the
                     // LDS table too, zero-padded groups of four 0.352; this form with zero-padded groups of four 0.345, of eight 0.388, of
@@ -589,22 +596,47 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
                             const f32x2 v10 = *(lds_v2 *)(q_ + ALY * FLZ * 8), v11 = *(lds_v2 *)(q_ + (ALY + 1) * FLZ * 8); \
                             /* weight = one half of an aligned register pair, broadcast to both images by op_sel (the compiler   */ \
                             /* copies W.w to a fresh register first: one v_mov per entry)                                          */ \
+                            FT2_FMAS(J, W)                                                                                  \
+                        }
+#if TOMO_FWD_TAB_W == 1
+#define FT2_FMAS(J, W)                                                                                                     \
                             const f32x2 w01_ = {(W).x, (W).y}, w23_ = {(W).z, (W).w};                                       \
                             asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(Pa) : "v"(w01_), "v"(v00));          \
                             asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(Pb) : "v"(w01_), "v"(v01));             \
                             asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(Pa) : "v"(w23_), "v"(v10));          \
-                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(Pb) : "v"(w23_), "v"(v11));             \
-                        }
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(Pb) : "v"(w23_), "v"(v11));
+#define FT2_W(J) tw[j4 + (J)]
+                    typedef float4 ft2_w_t;
+#elif TOMO_FWD_TAB_W == 2      /* measurement variant: w00, w01 by v_readlane, w10, w11 from the table (ds_read_b64) */
+#define FT2_FMAS(J, W)                                                                                                     \
+                            const f32x2 w23_ = {(W).x, (W).y};                                                              \
+                            Pa += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_w00), first + j4 + (J))) * v00; \
+                            Pb += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_w01), first + j4 + (J))) * v01; \
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(Pa) : "v"(w23_), "v"(v10));          \
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(Pb) : "v"(w23_), "v"(v11));
+#define FT2_W(J) ((const float2 *)tw)[j4 + (J)]
+                    typedef float2 ft2_w_t;
+#else                          /* measurement variant: all four weights by v_readlane, no table */
+#define FT2_FMAS(J, W)                                                                                                     \
+                            Pa += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_w00), first + j4 + (J))) * v00; \
+                            Pb += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_w01), first + j4 + (J))) * v01; \
+                            Pa += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_w10), first + j4 + (J))) * v10; \
+                            Pb += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_w11), first + j4 + (J))) * v11;
+#define FT2_W(J) 0
+                    typedef int ft2_w_t;
+#endif
                     int j4 = 0;
                     for (; j4 + 4 <= n_own; j4 += 4) {                                         // wave-uniform; four entries in flight, no padding
-                        const float4 wa = tw[j4], wb = tw[j4 + 1], wc = tw[j4 + 2], wd = tw[j4 + 3];
+                        const ft2_w_t wa = FT2_W(0), wb = FT2_W(1), wc = FT2_W(2), wd = FT2_W(3);
                         FT2_ENTRY(0, wa) FT2_ENTRY(1, wb) FT2_ENTRY(2, wc) FT2_ENTRY(3, wd)
                     }
                     for (; j4 < n_own; j4 += 1) {                                              // the 0 .. 3 entries left
-                        const float4 wa = tw[j4];
+                        const ft2_w_t wa = FT2_W(0);
                         FT2_ENTRY(0, wa)
-#undef FT2_ENTRY
                     }
+#undef FT2_ENTRY
+#undef FT2_FMAS
+#undef FT2_W
                 }
                 const f32x2 Pt = Pa + Pb;
                 const float S[2] = {Pt.x, Pt.y};
@@ -623,8 +655,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
                     const float val = wfz * S[k] + wcz * Sp1;
                     // the float atomics are this kernel's tightest bound (see the header) and are priced per 64-B unit touched: lanes whose
                     // value is 0 (rays that crossed only zero voxels of a live tile) do not take part, a row of zeros issues nothing
-                    const bool add = ray_ok[k] && val != 0.f;
-                    if (__builtin_amdgcn_ballot_w64(add) == 0) continue;
+                    const bool add = ray_ok[k] && val != 0.f;          // (an empty mask skips the instruction: s_cbranch_execz)
 #ifdef TOMO_ABLATE_FWD_ATOMICS          // measurement builds only (tools/gpu_r3l.sh): what the kernel costs without its atomics / with plain stores
 #if TOMO_ABLATE_FWD_ATOMICS == 2
                     if (add) pr[k * FLZ] = val;
