@@ -465,40 +465,93 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_z(const AdjC *__rest
 //     128-plane work-groups a row instruction is 64 floats starting at ray 128 b + 64 k - floor(p0z): aligned whenever floor(p0z) is a
 //     multiple of 16 (0 in the nominal geometry) -- 4 units instead of 4.9 -- and a 1024-plane volume takes 8 work-groups in z, not 9.
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// The LIVE-BLOCK LIST of k_fwd_flat_tab.  A block (16 x 16 x 128 voxels + x, y halo) whose voxels are all zero adds nothing to any ray.
+// Until round 3 such a work-group found that out itself after staging its block and returned -- but a returning work-group still has to
+// be DISPATCHED: it waits for a whole free CU (1024 threads, 157 KB of LDS) like any other, in launch order.  Measured on one MI355X, 1024
+// angles per launch: a volume of ones in 768 of 1024 planes (6 of 8 blocks in z live) took 248 ms where the same 6 blocks alone
+// (a 1024 x 1024 x 768 volume) take 198 ms; the benchmark's SIRT iterate is such a volume (planes 159 .. 864 of 1024).  So the blocks are
+// classified first (k_fwd_live: one small work-group per block, stops at the first non-zero of each image; 5 GB of coalesced reads at
+// worst), the live ones compacted in launch order (k_fwd_compact: one work-group, ballot + prefix counts) and the forward's work-group i
+// takes block list[1 + i]; work-groups past list[0] return -- they sit at the END of the grid, where nothing queues behind them.
+// flags[b]: bit 0 = image 0 (planes z0 .. z0 + 63) holds a non-zero voxel, bit 1 = image 1.  b = zb + nzb * (ty + nty * tx).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwd_live(const float *__restrict__ vol, TomoGeomC g, int tile_x0, int nzb, int nty, unsigned char *__restrict__ flags)
+{
+    const int b = (int)blockIdx.x;
+    const int zb = b % nzb, ty = (b / nzb) % nty, tx = b / (nzb * nty);
+    const int z0 = zb * (2 * FLZ), y0 = -1 + ty * ATY, x0 = -1 + (tx + tile_x0) * ATX;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool in0 = z0 + lane < g.nz, in1 = z0 + FLZ + lane < g.nz;
+    bool nz0 = false, nz1 = false;
+    for (int c = wv; c < ALX * ALY; c += 4) {                        // a wave reads a column's 2 x 64 planes: 2 x 256 B, coalesced
+        const int gx = x0 + c / ALY, gy = y0 + c % ALY;
+        if (gx < 0 || gx >= g.nx || gy < 0 || gy >= g.ny) continue;
+        const float *col = vol + ((size_t)gx * g.ny + gy) * g.nz + z0 + lane;
+        if (in0) nz0 |= col[0] != 0.f;
+        if (in1) nz1 |= col[FLZ] != 0.f;
+        if (__builtin_amdgcn_ballot_w64(nz0) && __builtin_amdgcn_ballot_w64(nz1)) break;      // wave-uniform: both images known to be live
+    }
+    const int l0 = __syncthreads_or(nz0), l1 = __syncthreads_or(nz1);
+    if (threadIdx.x == 0) flags[b] = (unsigned char)((l0 ? 1 : 0) | (l1 ? 2 : 0));
+}
+
+__global__ __launch_bounds__(1024) void k_fwd_compact(const unsigned char *__restrict__ flags, int n, int *__restrict__ list)
+{
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + (int)threadIdx.x;
+        const bool live = i < n && flags[i] != 0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(live);
+        if (lane == 0) wsum[wv] = (int)__builtin_popcountll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wv; ++w) off += wsum[w];
+        if (live) list[1 + off + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;      // launch order kept
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += wsum[w];
+            base += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) list[0] = base;
+}
+
 #ifndef TOMO_FWD_TAB_W
 #define TOMO_FWD_TAB_W 1         // where an entry's weights come from: 1 = the wave's LDS table (shipped); 0 / 2 = measurement variants (see the loop)
 #endif
 #define FT2_TAB 32
 #define FT2_TAB_ALLOC (FT2_TAB + 4)      // + 3 zero entries behind the owners (the loop runs in unmasked groups of four)
 __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
-                                                                const float *__restrict__ vol, TomoGeomC g, int tile_x0)
+                                                                const float *__restrict__ vol, TomoGeomC g, int tile_x0,
+                                                                const int *__restrict__ list, const unsigned char *__restrict__ flags, int nzb, int nty)
 {
     __shared__ __attribute__((aligned(16))) float img[ALX * ALY * FLZ * 2];                  // [x][y][plane][image]
     __shared__ float4 tab_w[FZ_WAVES * FT2_TAB_ALLOC];
     static_assert(sizeof(float) * ALX * ALY * FLZ * 2 + 16 * FZ_WAVES * FT2_TAB_ALLOC <= 160 * 1024, "LDS");
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // grid = (z work-groups, y tiles, x tiles), the z index ROTATED by the y tile index.  Work-groups are dealt to the 8 XCDs round-robin by
-    // linear id: with the plain z index fastest a 1024-plane volume (8 work-groups in z) pins each z range to ONE XCD, and the mostly
-    // empty top and bottom ranges of a phantom idle two XCDs (measured on the Shepp-Logan volume: 0.183 ms/angle against 0.137 with the y
-    // index fastest); with y fastest the work-groups in flight add to different sinogram rows (dense: 0.270 against 0.264 ms/angle with
-    // z fastest, whose concurrent work-groups add to neighbouring 512-B pieces of the same rows).  Rotated: both.
-    const int z0 = (int)((blockIdx.x + blockIdx.y) % gridDim.x) * (2 * FLZ), y0 = -1 + (int)blockIdx.y * ATY, x0 = -1 + ((int)blockIdx.z + tile_x0) * ATX;
-    bool live[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        bool any_nz = false;
-        for (int e = threadIdx.x; e < ALX * ALY * FLZ; e += FZ_WAVES * 64) {
-            const int lz = e % FLZ, t2 = e / FLZ, ly = t2 % ALY, lx = t2 / ALY;
-            const int gx = x0 + lx, gy = y0 + ly, gz = z0 + k * FLZ + lz;
-            float v = 0.f;
-            if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz) v = vol[((size_t)gx * g.ny + gy) * g.nz + gz];
-            img[e * 2 + k] = v;
-            any_nz |= (v != 0.f);
-        }
-        live[k] = __syncthreads_or(any_nz) != 0;                      // an all-zero tile contributes nothing to any ray
+    // work-group i takes the i-th LIVE block (k_fwd_live / k_fwd_compact above).  Consecutive work-groups go to consecutive XCDs: in list order
+    // (z fastest) the work-groups in flight add to neighbouring 512-B pieces of the same sinogram rows, and an empty z range idles no XCD.
+    if ((int)blockIdx.x >= list[0]) return;
+    const int blk = list[1 + blockIdx.x];
+    const int z0 = (blk % nzb) * (2 * FLZ), y0 = -1 + ((blk / nzb) % nty) * ATY, x0 = -1 + (blk / (nzb * nty) + tile_x0) * ATX;
+    const bool live[2] = {(flags[blk] & 1) != 0, (flags[blk] & 2) != 0};
+    for (int e = threadIdx.x; e < ALX * ALY * FLZ * 2; e += FZ_WAVES * 64) {          // e = ((lx * ALY + ly) * FLZ + lz) * 2 + image
+        const int k = e & 1, e1 = e >> 1;
+        const int lz = e1 % FLZ, t2 = e1 / FLZ, ly = t2 % ALY, lx = t2 / ALY;
+        const int gx = x0 + lx, gy = y0 + ly, gz = z0 + k * FLZ + lz;
+        float v = 0.f;
+        if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz < g.nz) v = vol[((size_t)gx * g.ny + gy) * g.nz + gz];
+        img[e] = v;
     }
-    if (!(live[0] || live[1])) return;
+    __syncthreads();
     const float bcx = (float)x0 + 0.5f * ATX, bcy = (float)y0 + 0.5f * ATY;
     const int64_t orgx = (int64_t)x0 << 32, orgy = (int64_t)y0 << 32;
     const size_t n_det = (size_t)g.ndx * g.ndz;

@@ -53,6 +53,10 @@ struct tomo_ctx {
     double *d_red = nullptr;
     double *h_red = nullptr;
     size_t red_cap = 0;     // doubles
+    // live-block list of the flat forward (grow-only): [0] = number of live blocks, [1 ..] their ids in launch order, then one flag byte per block
+    int *d_blk = nullptr;
+    size_t blk_ints = 0;
+    size_t fwd_blk_flat_ints = 0;       // ints of d_blk the flat forward of the current call uses (the general kernel's tile list follows)
     // general float workspace (grow-only): the TV-FISTA proximal step keeps its 7 fields here across calls
     float *d_ws = nullptr;
     size_t ws_elems = 0;
@@ -86,6 +90,7 @@ int tomo_fail(tomo_ctx *ctx, int code, const std::string &msg);
 int tomo_ensure_stage(tomo_ctx *ctx, size_t bytes);
 int tomo_ensure_red(tomo_ctx *ctx, size_t n_doubles);
 int tomo_ensure_ws(tomo_ctx *ctx, size_t n_floats);
+int tomo_ensure_blk(tomo_ctx *ctx, size_t n_ints);
 void tomo_prof_begin(tomo_ctx *ctx, const char *name);
 void tomo_prof_end(tomo_ctx *ctx);
 void tomo_prof_begin_on(tomo_ctx *ctx, const char *name, hipStream_t stream);

@@ -65,6 +65,7 @@ extern "C" int tomo_ctx_destroy(tomo_ctx *c)
     if (c->d_red) (void)hipFree(c->d_red);
     if (c->h_red) (void)hipHostFree(c->h_red);
     if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->d_blk) (void)hipFree(c->d_blk);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -191,6 +192,18 @@ int tomo_ensure_ws(tomo_ctx *ctx, size_t n)
     ctx->ws_elems = 0;
     TOMO_HIP(ctx, hipMalloc((void **)&ctx->d_ws, n * sizeof(float)));
     ctx->ws_elems = n;
+    return TOMO_OK;
+}
+
+int tomo_ensure_blk(tomo_ctx *ctx, size_t n)
+{
+    if (n <= ctx->blk_ints) return TOMO_OK;
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_blk) (void)hipFree(ctx->d_blk);
+    ctx->d_blk = nullptr;
+    ctx->blk_ints = 0;
+    TOMO_HIP(ctx, hipMalloc((void **)&ctx->d_blk, n * sizeof(int)));
+    ctx->blk_ints = n;
     return TOMO_OK;
 }
 

@@ -236,15 +236,27 @@ static int forward_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
     if (xt1 <= xt0) return TOMO_OK;
     grid.z = (unsigned)(xt1 - xt0);
     const AdjC *d_c = (const AdjC *)ctx->d_stage;
+    ctx->fwd_blk_flat_ints = 0;
     if (n_flat > 0) {
         dim3 fg = tile_grid(g, FTZ);
         fg.z = grid.z;
         if (ctx->fwd_flat_wide && xt0 == 0 && xt1 == (int)tile_grid(g).z)    // measurement variant: 32 x 16 footprint, one image (whole-volume calls only)
             TOMO_LAUNCH(ctx, "k_fwd_tile_flat", (k_fwd_flat_z<1, 32>), dim3(fg.x, fg.y, (g.nx + 1 + 31) / 32), dim3(FZ_WAVES * 64), 0, d_c, n_flat,
                         d_proj, d_vol, g, 0);
-        else if (fg.x >= 2 && ctx->fwd_flat_ztiles >= 2 && ctx->fwd_flat_tab)      // round 3: LDS sample table + image pairs
-            TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_fwd_flat_tab, dim3((g.nz + 2 * FLZ - 1) / (2 * FLZ), fg.y, fg.z), dim3(FZ_WAVES * 64), 0, d_c, n_flat,
-                        d_proj, d_vol, g, xt0);
+        else if (fg.x >= 2 && ctx->fwd_flat_ztiles >= 2 && ctx->fwd_flat_tab) {    // round 3: LDS sample table + image pairs, live blocks only
+            const int nzb = (g.nz + 2 * FLZ - 1) / (2 * FLZ), nty = (int)fg.y;
+            const size_t n_blk = (size_t)nzb * nty * fg.z;
+            if (n_blk >= (size_t)1 << 30) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_forward: volume too large for the flat forward's block list");
+            ctx->fwd_blk_flat_ints = 1 + n_blk + (n_blk + 3) / 4;       // the general kernel's tile list of the same call goes behind it
+            rc = tomo_ensure_blk(ctx, ctx->fwd_blk_flat_ints + (n_proj > n_flat ? 1 + (size_t)grid.x * grid.y * grid.z * 5 / 4 + 1 : 0));
+            if (rc) return rc;
+            int *d_list = ctx->d_blk;
+            unsigned char *d_flags = (unsigned char *)(ctx->d_blk + 1 + n_blk);
+            TOMO_LAUNCH(ctx, "k_fwd_live", k_fwd_live, dim3((unsigned)n_blk), dim3(256), 0, d_vol, g, xt0, nzb, nty, d_flags);
+            TOMO_LAUNCH(ctx, "k_fwd_live", k_fwd_compact, dim3(1), dim3(1024), 0, d_flags, (int)n_blk, d_list);
+            TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_fwd_flat_tab, dim3((unsigned)n_blk), dim3(FZ_WAVES * 64), 0, d_c, n_flat, d_proj, d_vol, g, xt0,
+                        (const int *)d_list, (const unsigned char *)d_flags, nzb, nty);
+        }
         else if (fg.x >= 2 && ctx->fwd_flat_ztiles >= 2)         // two z-adjacent tiles per work-group share the per-row set-up
             TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_fwd_flat_z<2>, dim3((fg.x + 1) / 2, fg.y, fg.z), dim3(FZ_WAVES * 64), 0, d_c, n_flat,
                         d_proj, d_vol, g, xt0);
@@ -252,9 +264,20 @@ static int forward_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
             TOMO_LAUNCH(ctx, "k_fwd_tile_flat", k_tile_flat<true>, fg, dim3(ADJ_WAVES * 64), 0, d_c, n_flat, d_proj,
                         (float *)d_vol, g, (const unsigned *)nullptr, 1.f, xt0);
     }
-    if (n_proj > n_flat)
-        TOMO_LAUNCH(ctx, "k_fwd_tile", k_tile<true>, grid, dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, d_proj, (float *)d_vol,
-                    g, (const unsigned *)nullptr, 1.f, xt0);
+    if (n_proj > n_flat) {
+        // the general kernel over the LIVE tiles only (kernels_tile.hip.h, k_tile_live); its list sits behind the flat forward's in d_blk
+        const size_t n_tile = (size_t)grid.x * grid.y * grid.z;
+        const size_t flat_ints = ctx->fwd_blk_flat_ints;
+        if (n_tile >= (size_t)1 << 30) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_forward: volume too large for the tile list");
+        rc = tomo_ensure_blk(ctx, flat_ints + 1 + n_tile + (n_tile + 3) / 4);
+        if (rc) return rc;
+        int *t_list = ctx->d_blk + flat_ints;
+        unsigned char *t_flags = (unsigned char *)(t_list + 1 + n_tile);
+        TOMO_LAUNCH(ctx, "k_fwd_live", k_tile_live, dim3((unsigned)n_tile), dim3(256), 0, d_vol, g, xt0, (int)grid.x, (int)grid.y, t_flags);
+        TOMO_LAUNCH(ctx, "k_fwd_live", k_fwd_compact, dim3(1), dim3(1024), 0, (const unsigned char *)t_flags, (int)n_tile, t_list);
+        TOMO_LAUNCH(ctx, "k_fwd_tile", k_tile<true>, dim3((unsigned)n_tile), dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, d_proj, (float *)d_vol,
+                    g, (const unsigned *)nullptr, 1.f, xt0, (const int *)t_list, (int)grid.x, (int)grid.y);
+    }
     return TOMO_OK;
 }
 
@@ -378,7 +401,7 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
     }
     if (n_proj > n_flat)
         TOMO_LAUNCH(ctx, "k_adj_tile", k_tile<false>, grid, dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, (float *)d_proj, d_vol, g,
-                    (const unsigned *)d_absmax, (float)weight_bound, xt0);
+                    (const unsigned *)d_absmax, (float)weight_bound, xt0, (const int *)nullptr, 0, 0);
     return TOMO_OK;
 }
 

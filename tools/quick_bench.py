@@ -25,17 +25,25 @@ def poses(n_proj, tilt, rng):
     return _lib.poses_array(phi, a, b, xyz, np.zeros(3))
 
 
-def run(N, n_proj, what, tilt=True, reps=2, opts=None, shepp=False):
+def run(N, n_proj, what, tilt=True, reps=2, opts=None, shepp=False, nz=None):
     rng = np.random.default_rng(0)
-    geo = Geometry(n_proj, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
+    nz = nz or N
+    geo = Geometry(n_proj, np.array([N, N, nz]), np.ones(3), np.array([N, nz]), np.ones(2))
     be = HipBackend(geo)
     for k, v in (opts or {}).items():
         be.ctx.set_option(k, v)
-    vol = be.zeros(N ** 3); be.fill(vol, 1.0)
-    if shepp:
+    vol = be.zeros(N * N * nz); be.fill(vol, 1.0)
+    if shepp == 2:                      # ones in the planes [0.155 N, 0.845 N), zero above and below: the support of the benchmark's SIRT iterate
+        x = np.ones((N, N, N), np.float32)
+        x[:, :, :int(0.155 * N)] = 0
+        x[:, :, int(0.845 * N):] = 0
+        del vol
+        vol = be.upload(x.ravel())
+        del x
+    elif shepp:
         from tomography_alignment_amd.utilities.generate_phantom import SHEPP_LOGAN
         be.phantom(vol, (N, N, N), SHEPP_LOGAN)
-    prj = be.zeros(n_proj * N * N); be.fill(prj, 1.0)
+    prj = be.zeros(n_proj * N * nz); be.fill(prj, 1.0)
     P = poses(n_proj, tilt, rng)
     grad = be.empty(6 * N * N) if what == "pg" else None
     fn = {"fwd": lambda: be.forward(P, vol, prj), "adj": lambda: be.adjoint(P, prj, vol),
@@ -62,11 +70,12 @@ if __name__ == "__main__":
         opts = {}
         for kv in parts[3:]:
             k, v = kv.split("=")
-            if k in ("tilt", "shepp"):
+            if k in ("tilt", "shepp", "nz"):
                 continue
             opts[k] = int(v)
         tilt = 1.0
         for kv in parts[3:]:
             if kv.startswith("tilt="):
                 tilt = float(kv[5:])
-        run(N, n_proj, what, tilt=tilt, opts=opts, shepp=any(kv == 'shepp=1' for kv in parts[3:]))
+        run(N, n_proj, what, tilt=tilt, opts=opts, shepp=max([int(kv[6:]) for kv in parts[3:] if kv.startswith('shepp=')] or [0]),
+            nz=max([int(kv[3:]) for kv in parts[3:] if kv.startswith('nz=')] or [0]) or None)
