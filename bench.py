@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-volume SIRT side measurement")
     ap.add_argument("--force-sharded", action="store_true",
                     help="N=1 only: run the multi-GPU code path (sharded solver, x-slab pipelined all-reduce) on a 1-rank RCCL communicator")
+    ap.add_argument("--slabs", type=int, default=None, help="x slabs of the sharded solver's pipelined iteration (default: the solver's own)")
     ap.add_argument("--fwd-variant", type=int, default=None)
     ap.add_argument("--adj-variant", type=int, default=None)
     args = ap.parse_args()
@@ -202,6 +203,9 @@ def main():
         be.fill(one, 0.05)
         be.axpy(vol, one, 1.0)
         del one
+
+    if args.slabs is not None:
+        sirt_mpi.SIRT.n_pipeline_slabs = int(args.slabs)
 
     def make_solver(tilted):
         alpha, beta, xyz = poses_for(tilted)

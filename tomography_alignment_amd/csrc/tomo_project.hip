@@ -376,7 +376,7 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
             // one-dimensional grid of patches (see the kernel): ceil(#patches / 8) groups of 8 patches x GPX*GPY tiles
             const int ntx = (xe - xs + GTX - 1) / GTX, nty = (g.ny + GTY - 1) / GTY, nzq = (g.nz + 64 * GWAVES - 1) / (64 * GWAVES);
             const long long n_patch = (long long)nzq * ((ntx + GPX - 1) / GPX) * ((nty + GPY - 1) / GPY);
-            const int patched = n_patch >= 256 ? 1 : 0;
+            const int patched = n_patch >= 64 ? 1 : 0;       // (256 until round 3: the sharded solver's x slabs -- 88 .. 176 patches at 1024^3 -- ran unpatched, 10 % slower)
             const long long n_wg = patched ? ((n_patch + 7) / 8) * 8 * (GPX * GPY) : (long long)nzq * ntx * nty;
             if (n_wg >= ((long long)1 << 31)) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "gather adjoint: grid too large");
             const dim3 ggrid((unsigned)n_wg);
