@@ -28,8 +28,10 @@
 #define GPITCH 68          // LDS row pitch in dwords: a multiple of 4, so that a row's plane quads (p .. p+3) are 16-byte aligned for ds_read_b128; rows r, r+1, ...
                            // of one plane quad fall in different bank quads (4 r + p mod 64)
 #define GWAVES 4
+#ifndef GPX
 #define GPX 8              // (x, y) tile patch that one XCD's resident work-groups cover together
 #define GPY 12
+#endif
 
 struct GfC {
     int64_t fp0x, fp0y, fux, fuy, fdx, fdy;   // x, y of the 32.32 lattice  p = fp0 + ix fu + j fd
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
     //          while the previous projection accumulates.
     float4 tn;
     int ix_lo_n;
-    float y0v[GROWS], yedge;                                           // yedge: lane r holds row r one plane below the wave's first
+    float y0v[GROWS], yedge = 0.f;                                         // yedge: lane r holds row r one plane below the wave's first
 #define G_SETUP(IPX)                                                                                                       \
     {                                                                                                                      \
         tn = wtab[((IPX) / GWAVES) % 3][(IPX) % GWAVES][lane];                                                             \
@@ -145,8 +147,10 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
                 y0v[r] = *(const float *)(srow + (o0 + (uint32_t)__builtin_amdgcn_readlane((int)rowoff, r)));              \
             /* the plane below (iz0 - 1) is the neighbouring lane's value (DPP shift when used); lane 0 has no neighbour: one  */ \
             /* more load, lane r fetching row r at the wave's first plane - 1 -- 15 loads per projection instead of 28      */ \
-            const uint32_t oe = (uint32_t)min(max(z0 - cn.zc - 1, 0), g.ndz - 1) * 4u;                                      \
-            yedge = *(const float *)(srow + (rowoff + oe));                                                                \
+            if (cn.tau != 0.f) {                                            /* (tau = 0: the plane below is never used) */ \
+                const uint32_t oe = (uint32_t)min(max(z0 - cn.zc - 1, 0), g.ndz - 1) * 4u;                                  \
+                yedge = *(const float *)(srow + (rowoff + oe));                                                            \
+            }                                                                                                              \
         }                                                                                                                  \
     }
     const int n_grp = (n_proj + GWAVES - 1) / GWAVES;
@@ -179,8 +183,13 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
         wrows[r * GPITCH + lane] = fmaf(c.tau, a1 - a0, a0);                                                                      \
     }
                 if (c.tau == 0.f) {                                         // samples sit exactly on detector rows (integer z shift: the nominal geometry
-#pragma unroll                                                              //  before alignment): Yz = y -- no neighbour plane, no lerp (fma(0, a1 - a0, a0) = a0)
-                    for (int r = 0; r < GROWS; ++r) wrows[r * GPITCH + lane] = select_lanes(y0v[r], m0);
+                    if (m0 == ~0ull) {                                      //  before alignment): Yz = y -- no neighbour plane, no lerp (fma(0, a1 - a0, a0) = a0)
+#pragma unroll
+                        for (int r = 0; r < GROWS; ++r) wrows[r * GPITCH + lane] = y0v[r];            // all 64 planes on the detector: no select either
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < GROWS; ++r) wrows[r * GPITCH + lane] = select_lanes(y0v[r], m0);
+                    }
                 }
                 else if ((m0 & m1) == ~0ull) { G_ZLERP(false) }             // all 64 planes and their lower neighbours on the detector: the usual case
                 else { G_ZLERP(true) }
