@@ -27,7 +27,9 @@
 #define GROWS 14          // rows a tile can touch: i0 spreads over <= 7 (|m00| + |m01|) <= 10.2 -> 11 values, + 3
 #define GPITCH 68          // LDS row pitch in dwords: a multiple of 4, so that a row's plane quads (p .. p+3) are 16-byte aligned for ds_read_b128; rows r, r+1, ...
                            // of one plane quad fall in different bank quads (4 r + p mod 64)
+#ifndef GWAVES
 #define GWAVES 4
+#endif
 #ifndef GPX
 #define GPX 8              // (x, y) tile patch that one XCD's resident work-groups cover together
 #define GPY 12
@@ -41,7 +43,7 @@ struct GfC {
 };
 
 template <int NJ>      // samples per row that can reach a column: 3 for step >= 0.95 voxel, 6 for step >= 0.475
-__global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *__restrict__ cs, int n_proj, const float *__restrict__ proj,
+__global__ __launch_bounds__(GWAVES * 64, 16 / GWAVES) void k_adj_gather_flat(const GfC *__restrict__ cs, int n_proj, const float *__restrict__ proj,
                                                                  float *__restrict__ vol, TomoGeomC g, int xs, int xe, int patched)
 {
     __shared__ __attribute__((aligned(16))) float rows[GWAVES][GROWS * GPITCH];
@@ -128,6 +130,11 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
     float4 tn;
     int ix_lo_n;
     float y0v[GROWS], yedge = 0.f;                                         // yedge: lane r holds row r one plane below the wave's first
+#ifdef TOMO_ABLATE_GATHER_LOADS     /* measurement builds only: the kernel without its sinogram loads (wrong sums) */
+#define G_ROW_LOAD(P) __int_as_float(0x3f800000 + (int)(size_t)(P))
+#else
+#define G_ROW_LOAD(P) (*(const float *)(P))
+#endif
 #define G_SETUP(IPX)                                                                                                       \
     {                                                                                                                      \
         tn = wtab[((IPX) / GWAVES) % 3][(IPX) % GWAVES][lane];                                                             \
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(GWAVES * 64, 4) void k_adj_gather_flat(const GfC *_
             const uint32_t o0 = (uint32_t)min(max(iz0, 0), g.ndz - 1) * 4u;                                                 \
             const uint32_t rowoff = (uint32_t)min(max(ix_lo_n + min(lane, GROWS - 1), 0), g.ndx - 1) * pitch4;              \
             _Pragma("unroll") for (int r = 0; r < GROWS; ++r)                                                              \
-                y0v[r] = *(const float *)(srow + (o0 + (uint32_t)__builtin_amdgcn_readlane((int)rowoff, r)));              \
+                y0v[r] = G_ROW_LOAD(srow + (o0 + (uint32_t)__builtin_amdgcn_readlane((int)rowoff, r)));                     \
             /* the plane below (iz0 - 1) is the neighbouring lane's value (DPP shift when used); lane 0 has no neighbour: one  */ \
             /* more load, lane r fetching row r at the wave's first plane - 1 -- 15 loads per projection instead of 28      */ \
             if (cn.tau != 0.f) {                                            /* (tau = 0: the plane below is never used) */ \
