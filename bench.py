@@ -241,7 +241,7 @@ def main():
     # ---- per-kernel timing of the timed region (HIP events on the stream each kernel / collective runs on)
     kern = {}
     for name in ("k_fwd_v1", "k_fwd_v2", "k_fwd_tile", "k_fwd_tile_flat", "k_fwd_live", "k_adj_v1", "k_adj_tile", "k_adj_tile_flat", "k_adj_gather_flat", "k_pad", "k_unpad",
-                 "k_absmax", "k_residual_scale", "k_update", "k_vec", "allreduce_f32", "comm_join_wait"):
+                 "k_absmax", "k_sino_zflags", "k_residual_scale", "k_update", "k_vec", "allreduce_f32", "comm_join_wait"):
         n, ms = ctx.profile_get(name)
         if n:
             # a pass over all angles may be issued as several launches (x slabs of the pipelined back-projection):

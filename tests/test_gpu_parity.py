@@ -392,6 +392,34 @@ def test_flat_forward_kernel_variants(PM, orc, shape, ndet, step):
     ctx.set_option("fwd_flat_tab", TAB_DEFAULT)
 
 
+@pytest.mark.parametrize("band", [(100, 141), (0, 3), (297, 310), (150, 151)])
+def test_gather_adjoint_with_empty_sinogram_planes(PM, orc, band):
+    """The gather back-projection skips the 64-plane chunks of the volume that can only receive from all-zero detector-z planes of the
+    sinogram (k_sino_zflags): a sinogram that is non-zero in a band of planes only, integer AND fractional z translations that differ per
+    projection (the band reaches different voxel planes per projection), z extent of five chunks -- against the oracle's exact adjoint,
+    and against the same call on a dense sinogram restricted by linearity."""
+    rng = np.random.default_rng(11)
+    shape, ndet, n_proj = (24, 20, 300), (24, 310), 5
+    phi = np.array([0.0, 0.7, np.pi / 2, 2.4, 3.0])
+    xyz = np.zeros((n_proj, 3))
+    xyz[:, 0] = rng.uniform(-2, 2, n_proj)
+    xyz[:, 2] = np.array([0.0, -7.0, 3.4, 12.0, -0.6])
+    geo, og = geo_pair(n_proj, None, shape=shape, ndet=ndet)
+    y = np.zeros((n_proj, ndet[0], ndet[1]), np.float32)
+    y[:, :, band[0]:band[1]] = rng.uniform(0.1, 1.0, (n_proj, ndet[0], band[1] - band[0]))
+    P = PM(geo)
+    A = P.projection_matrix(phi=phi, xyz_shift=xyz)
+    ctx = P.backend.ctx
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    got = A.T.dot(y.ravel())
+    ctx.profile_enable(False)
+    assert ctx.profile_get("k_adj_gather_flat")[0] == 1 and ctx.profile_get("k_sino_zflags")[0] == 1
+    want = orc.adjoint(og, y.ravel(), phi=phi, xyz_shift=xyz)
+    assert rel_max(got, want) < TOL
+    assert np.count_nonzero(got) > 0
+
+
 def test_mixed_tilted_and_untilted_call(PM, orc):
     rng = np.random.default_rng(13)
     geo, og = geo_pair(4, 24)

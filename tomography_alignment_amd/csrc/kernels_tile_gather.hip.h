@@ -42,9 +42,21 @@ struct GfC {
     int32_t n, zc, slot;
 };
 
+// flags[iz] = 1 when ANY value of the sinogram in detector-z plane iz is not zero (all projections, all rows of the call).  Thread = plane
+// (coalesced), work-groups stride over the n_rows = n_proj * ndx rows; flags pre-zeroed, benign races (everybody stores 1).
+__global__ __launch_bounds__(256) void k_sino_zflags(const float *__restrict__ proj, long long n_rows, int ndz, unsigned char *__restrict__ flags)
+{
+    const int iz = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (iz >= ndz) return;
+    bool nz = false;
+    for (long long r = blockIdx.y; r < n_rows; r += gridDim.y) nz |= proj[(size_t)r * ndz + iz] != 0.f;
+    if (nz) flags[iz] = 1;
+}
+
 template <int NJ>      // samples per row that can reach a column: 3 for step >= 0.95 voxel, 6 for step >= 0.475
 __global__ __launch_bounds__(GWAVES * 64, 16 / GWAVES) void k_adj_gather_flat(const GfC *__restrict__ cs, int n_proj, const float *__restrict__ proj,
-                                                                 float *__restrict__ vol, TomoGeomC g, int xs, int xe, int patched)
+                                                                 float *__restrict__ vol, TomoGeomC g, int xs, int xe, int patched,
+                                                                 const unsigned char *__restrict__ zflags, int zc_lo, int zc_hi)
 {
     __shared__ __attribute__((aligned(16))) float rows[GWAVES][GROWS * GPITCH];
     __shared__ float4 wtab[3][GWAVES][64];          // [group mod 3][projection of the group][column] = (i0, W0, W1, W2)
@@ -75,7 +87,23 @@ __global__ __launch_bounds__(GWAVES * 64, 16 / GWAVES) void k_adj_gather_flat(co
     }
     const int x0 = xs + tx * GTX, y0 = ty * GTY, z0 = (zq * GWAVES + wv) * 64;
     if (tx >= ntx || ty >= nty || zq >= nzq) return;                    // uniform over the WORK-GROUP (barriers below)
-    const bool zlive = z0 < g.nz;                                       // a wave past the volume still computes its share of tables
+    // a wave past the volume still computes its share of tables; so does one whose 64 planes Z can only receive zeros: plane Z gathers from the
+    // sinogram planes Z - zc and Z - zc - 1 (zc in [zc_lo, zc_hi] over the projections), and k_sino_zflags marked the planes that hold anything
+    bool zlive = z0 < g.nz;
+    if (zlive) {
+        bool any = false;
+        for (int i = z0 - zc_hi - 1 + lane; i <= z0 + 63 - zc_lo; i += 64) any |= i >= 0 && i < g.ndz && zflags[i] != 0;
+        zlive = __builtin_amdgcn_ballot_w64(any) != 0;
+    }
+    // Only the LIVE waves stay: nl of them, this one the rk-th.  They share the weight tables among themselves (a wave that has ended is not
+    // waited for by s_barrier); a work-group none of whose z chunks can receive anything ends here (its voxels keep what they hold).
+    __shared__ int wlive[GWAVES];
+    if (lane == 0) wlive[wv] = zlive ? 1 : 0;
+    __syncthreads();
+    int nl = 0, rk = 0;
+#pragma unroll
+    for (int w = 0; w < GWAVES; ++w) { nl += wlive[w]; rk += w < wv ? wlive[w] : 0; }
+    if (!zlive) return;
     // a lane is a voxel COLUMN (X, Y) with 64 plane accumulators, except while loading sinogram rows, where it is plane Zl
     const int X = x0 + (lane >> 3), Y = y0 + (lane & 7), Zl = z0 + lane;
     float *wrows = rows[wv];
@@ -87,11 +115,11 @@ __global__ __launch_bounds__(GWAVES * 64, 16 / GWAVES) void k_adj_gather_flat(co
     for (int p = 0; p < 32; ++p) acc2[p] = f32x2{0.f, 0.f};
 
     // ---- 1. the weight table of this lane's column for projection IPX -> wtab[GRP % 3][IPX % GWAVES][lane].  The table does not
-    //         depend on z: the four waves share it, wave w computes the projections 4 g + w (one barrier per four projections).
+    //         depend on z: the nl live waves share it, the rk-th computes the projections nl g + rk (one barrier per nl projections).
     //   candidates: rows i0..i0+2, samples j0..j0+NJ-1 (the footprint |dx|,|dy| < 1 maps to |d ix| <= |m00|+|m01| < 1.5: three
     //   consecutive integers cover an interval shorter than 3; likewise |d j| <= |m10|+|m11| < NJ/2); W_k from exact 32.32
     //   positions relative to the voxel
-#define G_TABLE(IPX)                                                                                                       \
+#define G_TABLE(IPX, BUF, SLOT)                                                                                            \
     {                                                                                                                      \
         float4 t4 = {0.f, 0.f, 0.f, 0.f};                                                                                  \
         if ((IPX) < n_proj) {                                                                                              \
@@ -120,7 +148,7 @@ __global__ __launch_bounds__(GWAVES * 64, 16 / GWAVES) void k_adj_gather_flat(co
             }                                                                                                              \
             t4.x = __builtin_bit_cast(float, i0); t4.y = W[0]; t4.z = W[1]; t4.w = W[2];                                   \
         }                                                                                                                  \
-        wtab[((IPX) / GWAVES) % 3][(IPX) % GWAVES][lane] = t4;                                                             \
+        wtab[BUF][SLOT][lane] = t4;                                                                                        \
     }
     // ---- 2a. fetch projection IPX's table entry and ISSUE the 15 loads of the sinogram rows the tile can touch: rows
     //          ix_lo .. ix_lo+13 at this lane's PLANE (coalesced) plus one gather of their values one plane below the wave's
@@ -135,9 +163,9 @@ __global__ __launch_bounds__(GWAVES * 64, 16 / GWAVES) void k_adj_gather_flat(co
 #else
 #define G_ROW_LOAD(P) (*(const float *)(P))
 #endif
-#define G_SETUP(IPX)                                                                                                       \
+#define G_SETUP(IPX, BUF, SLOT)                                                                                            \
     {                                                                                                                      \
-        tn = wtab[((IPX) / GWAVES) % 3][(IPX) % GWAVES][lane];                                                             \
+        tn = wtab[BUF][SLOT][lane];                                                                                        \
         const int i0s = __builtin_bit_cast(int, tn.x);                                                                     \
         ix_lo_n = __builtin_amdgcn_readfirstlane(wave_min_i32(i0s));                                                       \
         if (zlive) {                                                                                                       \
@@ -160,16 +188,19 @@ __global__ __launch_bounds__(GWAVES * 64, 16 / GWAVES) void k_adj_gather_flat(co
             }                                                                                                              \
         }                                                                                                                  \
     }
-    const int n_grp = (n_proj + GWAVES - 1) / GWAVES;
+    const int n_grp = (n_proj + nl - 1) / nl;
+    int buf = 0;                                                        // table buffer of the current group (three in rotation)
     if (n_grp > 0) {
-        G_TABLE(wv)                                                     // group 0
+        G_TABLE(rk, 0, rk)                                              // group 0
         __syncthreads();
-        G_SETUP(0)
+        G_SETUP(0, 0, 0)
     }
     for (int grp = 0; grp < n_grp; ++grp) {
-        if (grp + 1 < n_grp) G_TABLE((grp + 1) * GWAVES + wv)           // next group's tables: a third buffer, nobody reads it yet
+        const int nbuf = buf == 2 ? 0 : buf + 1;
+        if (grp + 1 < n_grp) G_TABLE((grp + 1) * nl + rk, nbuf, rk)     // next group's tables: a third buffer, nobody reads it yet
         __syncthreads();                                                // ... and everybody is done with group grp - 1's buffer
-        for (int ip = grp * GWAVES; ip < min(n_proj, (grp + 1) * GWAVES); ++ip) {
+        const int g0 = grp * nl, g1 = min(n_proj, g0 + nl);
+        for (int ip = g0; ip < g1; ++ip) {
             const GfC &c = cs[ip];
             const float4 t = tn;
             const int i0 = __builtin_bit_cast(int, t.x), ix_lo = ix_lo_n;
@@ -202,7 +233,8 @@ __global__ __launch_bounds__(GWAVES * 64, 16 / GWAVES) void k_adj_gather_flat(co
                 else { G_ZLERP(true) }
 #undef G_ZLERP
             }
-            if (ip + 1 < n_proj) G_SETUP(ip + 1)                        // the next group's table is already published
+            if (ip + 1 < g1) G_SETUP(ip + 1, buf, ip + 1 - g0)
+            else if (ip + 1 < n_proj) G_SETUP(ip + 1, nbuf, 0)          // the next group's table is already published
             // ---- 3. accumulate, lane = column: its three rows start at slot0; plane p is an immediate offset.  The LDS rows were
             //         written by this same wave (LDS operations of a wave execute in order), no other wave touches them.
             if (hit) {
@@ -224,6 +256,7 @@ __global__ __launch_bounds__(GWAVES * 64, 16 / GWAVES) void k_adj_gather_flat(co
                 }
             }
         }
+        buf = nbuf;
     }
 #undef G_TABLE
 #undef G_SETUP

@@ -47,6 +47,7 @@ struct tomo_ctx {
     int tile_cache_opts = 0, tile_cache_nflat = 0, tile_cache_ngather = 0;
     bool tile_cache_ok = false;
     double tile_cache_wb = 2.0;
+    int tile_cache_zc_lo = 0, tile_cache_zc_hi = 0;   // range of the gather-eligible projections' integer z offsets (GfC::zc)
     double tile_cache_eb_max = 0.0;     // largest |m10| + |m11| of the gather-eligible projections staged (picks NJ)
     size_t tile_cache_gfoff = 0;
     // reduction scratch
