@@ -392,12 +392,13 @@ def test_flat_forward_kernel_variants(PM, orc, shape, ndet, step):
     ctx.set_option("fwd_flat_tab", TAB_DEFAULT)
 
 
+@pytest.mark.parametrize("tilted", [False, True])
 @pytest.mark.parametrize("band", [(100, 141), (0, 3), (297, 310), (150, 151)])
-def test_gather_adjoint_with_empty_sinogram_planes(PM, orc, band):
+def test_adjoint_with_empty_sinogram_planes(PM, orc, band, tilted):
     """The gather back-projection skips the 64-plane chunks of the volume that can only receive from all-zero detector-z planes of the
     sinogram (k_sino_zflags): a sinogram that is non-zero in a band of planes only, integer AND fractional z translations that differ per
-    projection (the band reaches different voxel planes per projection), z extent of five chunks -- against the oracle's exact adjoint,
-    and against the same call on a dense sinogram restricted by linearity."""
+    projection (the band reaches different voxel planes per projection), z extent of five chunks -- against the oracle's exact adjoint.
+    tilted: the general tile kernel, which skips a (tile, projection) whose rays all lie in all-zero planes (prefix counts of the flags)."""
     rng = np.random.default_rng(11)
     shape, ndet, n_proj = (24, 20, 300), (24, 310), 5
     phi = np.array([0.0, 0.7, np.pi / 2, 2.4, 3.0])
@@ -407,15 +408,17 @@ def test_gather_adjoint_with_empty_sinogram_planes(PM, orc, band):
     geo, og = geo_pair(n_proj, None, shape=shape, ndet=ndet)
     y = np.zeros((n_proj, ndet[0], ndet[1]), np.float32)
     y[:, :, band[0]:band[1]] = rng.uniform(0.1, 1.0, (n_proj, ndet[0], band[1] - band[0]))
+    alpha = np.deg2rad(np.array([1.5, -2.0, 0.7, 2.0, -1.0])) if tilted else np.zeros(n_proj)
+    beta = np.deg2rad(np.array([-1.0, 0.5, 2.0, -2.0, 1.2])) if tilted else np.zeros(n_proj)
     P = PM(geo)
-    A = P.projection_matrix(phi=phi, xyz_shift=xyz)
+    A = P.projection_matrix(alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz)
     ctx = P.backend.ctx
     ctx.profile_reset()
     ctx.profile_enable(True)
     got = A.T.dot(y.ravel())
     ctx.profile_enable(False)
-    assert ctx.profile_get("k_adj_gather_flat")[0] == 1 and ctx.profile_get("k_sino_zflags")[0] == 1
-    want = orc.adjoint(og, y.ravel(), phi=phi, xyz_shift=xyz)
+    assert ctx.profile_get("k_adj_tile" if tilted else "k_adj_gather_flat")[0] == 1 and ctx.profile_get("k_sino_zflags")[0] == (4 if tilted else 1)
+    want = orc.adjoint(og, y.ravel(), alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz)
     assert rel_max(got, want) < TOL
     assert np.count_nonzero(got) > 0
 

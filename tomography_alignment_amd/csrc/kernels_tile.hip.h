@@ -197,11 +197,49 @@ __global__ __launch_bounds__(256) void k_tile_live(const float *__restrict__ vol
     if (threadIdx.x == 0) flags[b] = (unsigned char)(l ? 1 : 0);
 }
 
-// list != nullptr (the forward): a 1-D grid, work-group i takes the i-th live tile (nzt, nty: the tile grid the ids index); nullptr: a 3-D grid of tiles
+// detector-z range [izl, izh] (clipped to the detector) of the rays that can own a sample in the tile whose owned box has centre bc: a linear
+// functional over a box = centre value +- sum |coef| * half-extent (+ 2e-2 for float32).  ONE definition for k_tile and k_tile_adj_live.
+__device__ __forceinline__ void tile_iz_range(const AdjC &c, const float bc[3], int ndz, float &izl, float &izh)
+{
+    const float qx = bc[0] - (float)c.p0[0], qy = bc[1] - (float)c.p0[1], qz = bc[2] - (float)c.p0[2];
+    const float m10 = (float)c.minv[1][0], m11 = (float)c.minv[1][1], m12 = (float)c.minv[1][2];
+    const float izm = m10 * qx + m11 * qy + m12 * qz;
+    const float izr = fabsf(m10) * (0.5f * ATX) + fabsf(m11) * (0.5f * ATY) + fabsf(m12) * (0.5f * ATZ) + 2e-2f;
+    izl = fmaxf(izm - izr, 0.f);
+    izh = fminf(izm + izr, (float)(ndz - 1));
+}
+// "some detector-z plane in reach of the tile holds a non-zero sinogram value" (zcum: prefix counts of k_sino_zflags' flags)
+__device__ __forceinline__ bool tile_iz_any(const int *__restrict__ zcum, int ndz, float izl, float izh)
+{
+    const int za = (int)izl, zb = min(ndz - 1, (int)izh + 1);
+    return zcum[zb + 1] != zcum[za];
+}
+
+// The general ADJOINT's live tiles: a tile none of whose projections can bring a non-zero sinogram value receives nothing.  One wave per
+// tile, lanes over the projections; the flagged tiles are compacted by k_fwd_compact and k_tile<false> takes them from the list -- like the
+// forward's all-zero tiles, a tile that only returns would still wait in launch order for room on a CU.
+__global__ __launch_bounds__(64) void k_tile_adj_live(const AdjC *__restrict__ pcs, int n_proj, TomoGeomC g, int tile_x0, int nzt, int nty,
+                                                      const int *__restrict__ zcum, unsigned char *__restrict__ flags)
+{
+    const int b = (int)blockIdx.x;
+    const int z0 = -1 + (b % nzt) * ATZ, y0 = -1 + ((b / nzt) % nty) * ATY, x0 = -1 + (b / (nzt * nty) + tile_x0) * ATX;
+    const float bc[3] = {(float)x0 + 0.5f * ATX, (float)y0 + 0.5f * ATY, (float)z0 + 0.5f * ATZ};
+    bool any = false;
+    for (int ip = threadIdx.x; ip < n_proj && !any; ip += 64) {
+        float izl, izh;
+        tile_iz_range(pcs[ip], bc, g.ndz, izl, izh);
+        any = !(izl > izh + 1.f) && tile_iz_any(zcum, g.ndz, izl, izh);
+    }
+    const bool live = __builtin_amdgcn_ballot_w64(any) != 0;
+    if (threadIdx.x == 0) flags[b] = live ? 1 : 0;
+}
+
+// list != nullptr: a 1-D grid, work-group i takes the i-th live tile (nzt, nty: the tile grid the ids index); nullptr: a 3-D grid of tiles
 template <bool FWD>
 __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
                                                          float *__restrict__ vol, TomoGeomC g, const unsigned *__restrict__ absmax_bits,
-                                                         float weight_bound, int tile_x0, const int *__restrict__ list, int nzt, int nty)
+                                                         float weight_bound, int tile_x0, const int *__restrict__ list, int nzt, int nty,
+                                                         const int *__restrict__ zcum)
 {
     __shared__ int acc[ALX * ALY * ALZ + 4];        // + pad: a masked-out lane may read one dword past the last row (its value is discarded)
     const lds_cfloat *img3 = (const lds_cfloat *)acc;       // explicit LDS pointer: offsets made opaque below must still give ds_read
@@ -251,16 +289,18 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
             // lattice-coordinate ranges of the owned box: a linear functional over a box = centre value +- sum |coef|*half-extent
             const float qx = bc[0] - (float)c.p0[0], qy = bc[1] - (float)c.p0[1], qz = bc[2] - (float)c.p0[2];
             const float m00 = (float)c.minv[0][0], m01 = (float)c.minv[0][1], m02 = (float)c.minv[0][2];
-            const float m10 = (float)c.minv[1][0], m11 = (float)c.minv[1][1], m12 = (float)c.minv[1][2];
             const float ixc = m00 * qx + m01 * qy + m02 * qz;
             const float ixr = fabsf(m00) * (0.5f * ATX) + fabsf(m01) * (0.5f * ATY) + fabsf(m02) * (0.5f * ATZ) + 2e-2f;
-            const float izm = m10 * qx + m11 * qy + m12 * qz;
-            const float izr = fabsf(m10) * (0.5f * ATX) + fabsf(m11) * (0.5f * ATY) + fabsf(m12) * (0.5f * ATZ) + 2e-2f;
             const int ix_lo = max(0, (int)ceilf(fmaxf(ixc - ixr, -1.f)));
             const int ix_hi = min(g.ndx - 1, (int)floorf(fminf(ixc + ixr, (float)g.ndx)));
             if (ix_lo > ix_hi) continue;
-            const float izl = fmaxf(izm - izr, 0.f), izh = fminf(izm + izr, (float)(g.ndz - 1));
+            float izl, izh;
+            tile_iz_range(c, bc, g.ndz, izl, izh);
             if (izl > izh + 1.f) continue;
+            // adjoint: every sample this tile owns belongs to a ray with iz in [izl, izh]; zcum[i] = number of detector-z planes < i of the
+            // call's sinogram that hold a non-zero value (tomo_project.hip: k_sino_zflags, k_zflags_prefix).  None in reach: the rays that
+            // own samples here carry zeros, the others own nothing here -- this (tile, projection) adds nothing
+            if (!FWD && zcum && !tile_iz_any(zcum, g.ndz, izl, izh)) continue;
             const float izc = 0.5f * (izl + izh), hs = 0.5f * (izh - izl) + 1.f;   // lanes' iz spread about the centre line
             const int n_rows_w = ix_hi - ix_lo + 1;
             const float fp0[3] = {(float)c.p0[0] - (float)x0, (float)c.p0[1] - (float)y0, (float)c.p0[2] - (float)z0};   // tile-relative
@@ -357,7 +397,10 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
                             // before: 1.52 -> 1.41 ms/angle at 1024^3)
                             f32x2 ksc = {-two_m32, two_m32}, kof = {1.f, 0.f};
                             asm("" : "+v"(kof));                        // held in a VGPR pair (else re-materialised per sample)
-                            for (int jj = 0; jj < cnt; ++jj) {
+                            // 64 rays whose sinogram values are all zero add integer zeros: skip them (wave-uniform; a residual sinogram is
+                            // exactly zero wherever the rays miss the object's support -- a third of the rows in the benchmark's SIRT step)
+                            const int cnt_a = __builtin_amdgcn_ballot_w64(ys != 0.f) ? cnt : 0;
+                            for (int jj = 0; jj < cnt_a; ++jj) {
                                 const unsigned lx = (unsigned)(px >> 32), ly = (unsigned)(py >> 32), lz = (unsigned)(pz >> 32);
                                 const float yo = select_lanes(ys, __builtin_amdgcn_ballot_w64((lx | ly) < (unsigned)ATX) & __builtin_amdgcn_ballot_w64(lz < (unsigned)ATZ));
                                 const unsigned cx = TILE_CLAMP(lx, ATX - 1), cy = TILE_CLAMP(ly, ATY - 1), cz = TILE_ZMASK(lz);      // unclamped: a non-owner adds integer 0 (tile_cell_dword)

@@ -53,6 +53,34 @@ __global__ __launch_bounds__(256) void k_sino_zflags(const float *__restrict__ p
     if (nz) flags[iz] = 1;
 }
 
+// cum[i] = number of flagged planes below i, i = 0 .. n (one work-group; the general adjoint asks "any flagged plane in [a, b]?" with two loads)
+__global__ __launch_bounds__(1024) void k_zflags_prefix(const unsigned char *__restrict__ flags, int n, int *__restrict__ cum)
+{
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + (int)threadIdx.x;
+        const bool f = i < n && flags[i] != 0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(f);
+        if (lane == 0) wsum[wv] = (int)__builtin_popcountll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wv; ++w) off += wsum[w];
+        if (i < n) cum[i] = off + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += wsum[w];
+            base += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cum[n] = base;
+}
+
 template <int NJ>      // samples per row that can reach a column: 3 for step >= 0.95 voxel, 6 for step >= 0.475
 __global__ __launch_bounds__(GWAVES * 64, 16 / GWAVES) void k_adj_gather_flat(const GfC *__restrict__ cs, int n_proj, const float *__restrict__ proj,
                                                                  float *__restrict__ vol, TomoGeomC g, int xs, int xe, int patched,

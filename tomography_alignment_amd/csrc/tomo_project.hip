@@ -282,7 +282,7 @@ static int forward_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
         TOMO_LAUNCH(ctx, "k_fwd_live", k_tile_live, dim3((unsigned)n_tile), dim3(256), 0, d_vol, g, xt0, (int)grid.x, (int)grid.y, t_flags);
         TOMO_LAUNCH(ctx, "k_fwd_live", k_fwd_compact, dim3(1), dim3(1024), 0, (const unsigned char *)t_flags, (int)n_tile, t_list);
         TOMO_LAUNCH(ctx, "k_fwd_tile", k_tile<true>, dim3((unsigned)n_tile), dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, d_proj, (float *)d_vol,
-                    g, (const unsigned *)nullptr, 1.f, xt0, (const int *)t_list, (int)grid.x, (int)grid.y);
+                    g, (const unsigned *)nullptr, 1.f, xt0, (const int *)t_list, (int)grid.x, (int)grid.y, (const int *)nullptr);
     }
     return TOMO_OK;
 }
@@ -375,6 +375,25 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
     if (xt1 <= xt0) return TOMO_OK;
     grid.z = (unsigned)(xt1 - xt0);
     const AdjC *d_c = (const AdjC *)ctx->d_stage;
+    // Which detector-z planes of this call's sinogram hold a non-zero value at all (any projection, any row)?  A residual sinogram is exactly
+    // zero wherever the rays miss the object's support: a wave of the gather kernel whose 64 voxel planes can only receive from all-zero
+    // planes skips its loads and its plane loop (zlive), the general kernel skips a (tile, projection) whose rays all lie in such planes
+    // (zcum: prefix counts of the flags).  One coalesced pass over the sinogram (0.8 ms for 4.3 GB); flags and counts live in d_blk.
+    unsigned char *d_zf = nullptr;
+    int *d_zcum = nullptr;
+    if (n_gather > 0 || n_proj > n_flat) {
+        const size_t zf_ints = ((size_t)g.ndz + 3) / 4;
+        const size_t n_tile_all = (size_t)grid.x * grid.y * grid.z;
+        rc = tomo_ensure_blk(ctx, zf_ints + (size_t)g.ndz + 1 + (n_proj > n_flat ? 1 + n_tile_all + (n_tile_all + 3) / 4 : 0));
+        if (rc) return rc;
+        d_zf = (unsigned char *)ctx->d_blk;
+        d_zcum = ctx->d_blk + zf_ints;
+        TOMO_HIP(ctx, hipMemsetAsync(d_zf, 0, (size_t)g.ndz, ctx->stream));
+        const long long n_rows = (long long)n_proj * g.ndx;
+        const unsigned gy = (unsigned)std::min<long long>(n_rows, 4096);
+        TOMO_LAUNCH(ctx, "k_sino_zflags", k_sino_zflags, dim3((unsigned)((g.ndz + 255) / 256), gy), dim3(256), 0, d_proj, n_rows, g.ndz, d_zf);
+        if (n_proj > n_flat) TOMO_LAUNCH(ctx, "k_sino_zflags", k_zflags_prefix, dim3(1), dim3(1024), 0, (const unsigned char *)d_zf, g.ndz, d_zcum);
+    }
     if (n_gather > 0) {
         // the voxel x range the tile columns [xt0, xt1) finalise (the tile grid starts at x = -1)
         const int xs = std::max(0, ATX * xt0 - 1), xe = (xt1 == n_xt) ? g.nx : std::min(g.nx, ATX * xt1 - 1);
@@ -386,18 +405,6 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
             const long long n_wg = patched ? ((n_patch + 7) / 8) * 8 * (GPX * GPY) : (long long)nzq * ntx * nty;
             if (n_wg >= ((long long)1 << 31)) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "gather adjoint: grid too large");
             const dim3 ggrid((unsigned)n_wg);
-            // which detector-z planes of this call's sinogram hold a non-zero value at all (any projection, any row): a wave whose 64 voxel
-            // planes can only receive from all-zero planes skips its loads and its plane loop (kernel: zlive).  One coalesced pass over the
-            // sinogram (1 ms for 4.3 GB); the flags live behind the forward's block lists in d_blk
-            rc = tomo_ensure_blk(ctx, ((size_t)g.ndz + 3) / 4);
-            if (rc) return rc;
-            unsigned char *d_zf = (unsigned char *)ctx->d_blk;
-            TOMO_HIP(ctx, hipMemsetAsync(d_zf, 0, (size_t)g.ndz, ctx->stream));
-            {
-                const long long n_rows = (long long)n_proj * g.ndx;
-                const unsigned gy = (unsigned)std::min<long long>(n_rows, 4096);
-                TOMO_LAUNCH(ctx, "k_sino_zflags", k_sino_zflags, dim3((unsigned)((g.ndz + 255) / 256), gy), dim3(256), 0, d_proj, n_rows, g.ndz, d_zf);
-            }
             const int zc_lo = ctx->tile_cache_zc_lo, zc_hi = ctx->tile_cache_zc_hi;
             if (ctx->tile_cache_eb_max < 1.49)
                 TOMO_LAUNCH(ctx, "k_adj_gather_flat", k_adj_gather_flat<3>, ggrid, dim3(GWAVES * 64), 0, d_gfc, n_gather, d_proj, d_vol, g, xs, xe, patched,
@@ -420,9 +427,23 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
         TOMO_LAUNCH(ctx, "k_adj_tile_flat", k_tile_flat<false>, fgrid, dim3(ADJ_WAVES * 64), 0, d_c + n_gather, n_flat - n_gather, (float *)d_proj,
                     d_vol, g, (const unsigned *)d_absmax, (float)weight_bound, xt0);
     }
-    if (n_proj > n_flat)
-        TOMO_LAUNCH(ctx, "k_adj_tile", k_tile<false>, grid, dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, (float *)d_proj, d_vol, g,
-                    (const unsigned *)d_absmax, (float)weight_bound, xt0, (const int *)nullptr, 0, 0);
+    if (n_proj > n_flat) {
+        // the tiles some projection can bring something to, compacted in launch order (kernels_tile.hip.h: k_tile_adj_live); list and flags
+        // sit behind the plane flags and their prefix counts in d_blk
+        const size_t n_tile = (size_t)grid.x * grid.y * grid.z;
+        if (n_tile >= (size_t)1 << 30) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_adjoint: volume too large for the tile list");
+        const size_t head = ((size_t)g.ndz + 3) / 4 + (size_t)g.ndz + 1;
+        rc = tomo_ensure_blk(ctx, head + 1 + n_tile + (n_tile + 3) / 4);      // (grows at most once per geometry: d_zf / d_zcum are re-derived below)
+        if (rc) return rc;
+        if ((unsigned char *)ctx->d_blk != d_zf) return tomo_fail(ctx, TOMO_ERR_STATE, "tomo_adjoint: block buffer moved");
+        int *t_list = ctx->d_blk + head;
+        unsigned char *t_flags = (unsigned char *)(t_list + 1 + n_tile);
+        TOMO_LAUNCH(ctx, "k_sino_zflags", k_tile_adj_live, dim3((unsigned)n_tile), dim3(64), 0, d_c + n_flat, n_proj - n_flat, g, xt0, (int)grid.x,
+                    (int)grid.y, (const int *)d_zcum, t_flags);
+        TOMO_LAUNCH(ctx, "k_sino_zflags", k_fwd_compact, dim3(1), dim3(1024), 0, (const unsigned char *)t_flags, (int)n_tile, t_list);
+        TOMO_LAUNCH(ctx, "k_adj_tile", k_tile<false>, dim3((unsigned)n_tile), dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, (float *)d_proj, d_vol, g,
+                    (const unsigned *)d_absmax, (float)weight_bound, xt0, (const int *)t_list, (int)grid.x, (int)grid.y, (const int *)d_zcum);
+    }
     return TOMO_OK;
 }
 
