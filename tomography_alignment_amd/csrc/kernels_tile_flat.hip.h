@@ -527,7 +527,7 @@ __global__ __launch_bounds__(1024) void k_fwd_compact(const unsigned char *__res
 #define TOMO_FWD_TAB_W 1         // where an entry's weights come from: 1 = the wave's LDS table (shipped); 0 / 2 = measurement variants (see the loop)
 #endif
 #define FT2_TAB 32
-#define FT2_TAB_ALLOC (FT2_TAB + 4)      // + 3 zero entries behind the owners (the loop runs in unmasked groups of four)
+#define FT2_TAB_ALLOC (FT2_TAB + 4)      // a wave's table: the owners' entries of one pass (<= FT2_TAB) + padding to a 64-B multiple
 __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
                                                                 const float *__restrict__ vol, TomoGeomC g, int tile_x0,
                                                                 const int *__restrict__ list, const unsigned char *__restrict__ flags, int nzb, int nty)
@@ -619,8 +619,8 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
                     const float wx = (float)(unsigned)px * two_m32, wy = (float)(unsigned)py * two_m32;
                     const float t_w11 = wx * wy, t_w10 = wx - t_w11, t_w01 = wy - t_w11, t_w00 = 1.f - wx - t_w01;
                     // the owned samples of a row are CONTIGUOUS lanes first .. first + n_own - 1 (see k_fwd_flat_z): entry i of the table =
-                    // lane first + i; three zero entries behind them let the loop run in unmasked groups of four.  LDS operations of
-                    // one wave execute in order: no barrier between these writes and the reads below, nor against the previous chunk's.
+                    // lane first + i.  LDS operations of one wave execute in order: no barrier between these writes and the reads below,
+                    // nor against the previous chunk's.
                     const int n_own = (int)__builtin_popcountll(om);
                     const int first = (int)__builtin_ctzll(om);
                     const unsigned slot = (unsigned)(lane - first);
