@@ -96,8 +96,8 @@ TOMO_API int tomo_sync(tomo_ctx *ctx);
  *   "tile_flat"   1 (default): untilted projections (alpha = beta = 0, detector-z pitch 1) take the flat tile kernels
  *   "fwd_flat_ztiles" 2 (default): the flat forward kernel owns two z-adjacent tiles per work-group and builds each detector
  *                 row's sample table once for both; 1: one tile per work-group
- *   "fwd_flat_tab" 1 (default): the two-z-tile flat forward keeps each row's sample table in LDS and the two images interleaved
- *                 per plane (k_fwd_flat_tab: 4 ds_read_b64 + 4 packed FMAs per sample, no cross-lane broadcasts); 0: the round-2
+ *   "fwd_flat_tab" 1 (default): the flat forward over 16 x 16 x 128-voxel blocks with the two 64-plane images interleaved per plane and
+ *                 each row's weights in an LDS table (k_fwd_flat_tab), run over the blocks that hold a non-zero voxel only; 0: the round-2
  *                 kernel (entries broadcast with v_readlane)
  *   "fwd_flat_wide" 0 (default); 1: measurement variant of the flat forward with a 32 x 16 x 63 tile footprint and one image
  *                 per work-group (half the tile crossings, hence half the sinogram atomics; whole-volume calls only)
@@ -105,7 +105,11 @@ TOMO_API int tomo_sync(tomo_ctx *ctx);
  *                 adjoint (accumulators in registers, no atomics) instead of the LDS-atomic flat tile kernel
  *   "reuse_staged_volume" 1: the caller vouches that the volume passed to tomo_proj_grad / tomo_cost_grad / the ray-driven
  *                 forward has not changed since the previous such call with the same pointer, so its zero-padded staging
- *                 copy is reused (alignment loops evaluate hundreds of poses against one volume); default 0 */
+ *                 copy is reused (alignment loops evaluate hundreds of poses against one volume); default 0
+ *   "reuse_sino_flags" 1: the caller vouches that the sinogram passed to tomo_adjoint / tomo_adjoint_xslab has not changed since the
+ *                 previous such call with the same pointer and number of projections, so the scan that marks its non-empty detector-z
+ *                 planes is not repeated (the x-slab calls of ONE back-projection pass: the solver sets it for slabs 2..n); default 0.
+ *                 Any forward call, and any call with another pointer or size, drops the cached marks */
 TOMO_API int tomo_set_option(tomo_ctx *ctx, const char *key, int value);
 
 /* Geometry: replaces passing a `Geometry` object to utilities/ray_voxel_utilities.py:53,113.

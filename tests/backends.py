@@ -103,7 +103,7 @@ class OracleBackend(object):
     def tiles_take(self, poses, proj, vol):
         return not self.declines_tiles
 
-    def adjoint_xslab(self, poses, proj, out, xt0, xt1):
+    def adjoint_xslab(self, poses, proj, out, xt0, xt1, same_sinogram=False):
         self._check_tiles()
         if xt1 <= xt0:
             return

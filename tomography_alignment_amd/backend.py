@@ -76,11 +76,18 @@ class HipBackend(object):
         self.ctx.check(self.lib.tomo_adjoint_xslab_info(self.ctx.handle, ctypes.byref(n), ctypes.byref(w)))
         return n.value, w.value
 
-    def adjoint_xslab(self, poses, proj, out, xt0, xt1):
+    def adjoint_xslab(self, poses, proj, out, xt0, xt1, same_sinogram=False):
         """A^T y restricted to the x tile columns [xt0, xt1); ADDS into `out` (zero it first).  Raises TomoError for poses
-        the tile kernels decline."""
+        the tile kernels decline.  same_sinogram: the caller vouches that `proj` is unchanged since the previous back-projection
+        call (the later slabs of one pass) -- its non-empty detector planes are then not looked for again."""
         self._geom()
-        self.ctx.check(self.lib.tomo_adjoint_xslab(self.ctx.handle, _lib.dptr(poses), poses.shape[0], proj.ptr, out.ptr, int(xt0), int(xt1)))
+        if same_sinogram:
+            self.ctx.set_option("reuse_sino_flags", 1)
+        try:
+            self.ctx.check(self.lib.tomo_adjoint_xslab(self.ctx.handle, _lib.dptr(poses), poses.shape[0], proj.ptr, out.ptr, int(xt0), int(xt1)))
+        finally:
+            if same_sinogram:
+                self.ctx.set_option("reuse_sino_flags", 0)
 
     def forward_xslab(self, poses, vol, out, xt0, xt1):
         """The partial ray sums of the x tile columns [xt0, xt1) (they read only the voxels x in [w*xt0 - 1, w*xt1]); ADDS into

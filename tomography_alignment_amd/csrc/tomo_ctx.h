@@ -57,6 +57,10 @@ struct tomo_ctx {
     // live-block list of the flat forward (grow-only): [0] = number of live blocks, [1 ..] their ids in launch order, then one flag byte per block
     int *d_blk = nullptr;
     size_t blk_ints = 0;
+    int reuse_sino_flags = 0;           // option: the caller vouches the sinogram of the previous back-projection call is unchanged
+    const void *zf_src = nullptr;       // sinogram whose plane flags (+ prefix counts when zf_has_cum) d_blk currently holds; nullptr: none
+    int zf_nproj = 0;
+    bool zf_has_cum = false;
     size_t fwd_blk_flat_ints = 0;       // ints of d_blk the flat forward of the current call uses (the general kernel's tile list follows)
     // general float workspace (grow-only): the TV-FISTA proximal step keeps its 7 fields here across calls
     float *d_ws = nullptr;

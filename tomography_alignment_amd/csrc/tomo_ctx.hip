@@ -148,6 +148,7 @@ extern "C" int tomo_set_option(tomo_ctx *ctx, const char *key, int value)
     else if (!strcmp(key, "fwd_flat_wide")) ctx->fwd_flat_wide = value;
     else if (!strcmp(key, "fwd_flat_tab")) ctx->fwd_flat_tab = value;
     else if (!strcmp(key, "reuse_staged_volume")) ctx->reuse_staged = value;
+    else if (!strcmp(key, "reuse_sino_flags")) ctx->reuse_sino_flags = value;
     else return tomo_fail(ctx, TOMO_ERR_ARG, std::string("unknown option ") + key);
     return TOMO_OK;
 }
@@ -198,6 +199,7 @@ int tomo_ensure_ws(tomo_ctx *ctx, size_t n)
 int tomo_ensure_blk(tomo_ctx *ctx, size_t n)
 {
     if (n <= ctx->blk_ints) return TOMO_OK;
+    ctx->zf_src = nullptr;                              // the buffer is replaced: cached plane flags go with it
     TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_blk) (void)hipFree(ctx->d_blk);
     ctx->d_blk = nullptr;

@@ -243,6 +243,7 @@ static int forward_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
     grid.z = (unsigned)(xt1 - xt0);
     const AdjC *d_c = (const AdjC *)ctx->d_stage;
     ctx->fwd_blk_flat_ints = 0;
+    ctx->zf_src = nullptr;                  // the block lists below overwrite the back-projection's cached plane flags in d_blk
     if (n_flat > 0) {
         dim3 fg = tile_grid(g, FTZ);
         fg.z = grid.z;
@@ -388,11 +389,19 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
         if (rc) return rc;
         d_zf = (unsigned char *)ctx->d_blk;
         d_zcum = ctx->d_blk + zf_ints;
-        TOMO_HIP(ctx, hipMemsetAsync(d_zf, 0, (size_t)g.ndz, ctx->stream));
-        const long long n_rows = (long long)n_proj * g.ndx;
-        const unsigned gy = (unsigned)std::min<long long>(n_rows, 4096);
-        TOMO_LAUNCH(ctx, "k_sino_zflags", k_sino_zflags, dim3((unsigned)((g.ndz + 255) / 256), gy), dim3(256), 0, d_proj, n_rows, g.ndz, d_zf);
-        if (n_proj > n_flat) TOMO_LAUNCH(ctx, "k_sino_zflags", k_zflags_prefix, dim3(1), dim3(1024), 0, (const unsigned char *)d_zf, g.ndz, d_zcum);
+        const bool want_cum = n_proj > n_flat;
+        // (option "reuse_sino_flags": the x-slab calls of one back-projection pass scan the sinogram once, not once per slab)
+        const bool cached = ctx->reuse_sino_flags && ctx->zf_src == (const void *)d_proj && ctx->zf_nproj == n_proj && (ctx->zf_has_cum || !want_cum);
+        if (!cached) {
+            TOMO_HIP(ctx, hipMemsetAsync(d_zf, 0, (size_t)g.ndz, ctx->stream));
+            const long long n_rows = (long long)n_proj * g.ndx;
+            const unsigned gy = (unsigned)std::min<long long>(n_rows, 4096);
+            TOMO_LAUNCH(ctx, "k_sino_zflags", k_sino_zflags, dim3((unsigned)((g.ndz + 255) / 256), gy), dim3(256), 0, d_proj, n_rows, g.ndz, d_zf);
+            if (want_cum) TOMO_LAUNCH(ctx, "k_sino_zflags", k_zflags_prefix, dim3(1), dim3(1024), 0, (const unsigned char *)d_zf, g.ndz, d_zcum);
+            ctx->zf_src = (const void *)d_proj;
+            ctx->zf_nproj = n_proj;
+            ctx->zf_has_cum = want_cum;
+        }
     }
     if (n_gather > 0) {
         // the voxel x range the tile columns [xt0, xt1) finalise (the tile grid starts at x = -1)

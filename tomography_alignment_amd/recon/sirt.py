@@ -154,14 +154,14 @@ class SIRT(object):
         self.proj_mat.apply(self.d_rec, self.d_ax)
 
     def _update(self, positivity, last=False):
-        """rec += d_bp (already scaled by V), clamp; returns ||gt - rec||^2 when a ground truth is given."""
-        return self.be.update(self.d_rec, self.d_bp, None, positivity, self.d_gt)
+        """rec += V * d_bp, clamp; returns ||gt - rec||^2 when a ground truth is given."""
+        return self.be.update(self.d_rec, self.d_bp, self.d_V, positivity, self.d_gt)
 
     def _backproject_scaled(self):
-        """d_bp = V * A^T d_res, summed over the angle shards."""
-        be = self.be
+        """d_bp = A^T d_res, summed over the angle shards.  The reference scales by V here (sirt.py:63) and, sharded, BEFORE its Allreduce
+        (sirt_mpi.py:101-103); V is the same on every rank, so the scaling commutes with the sum and is applied by the update
+        (`rec += V * bp` in one pass) -- one read-modify-write of the volume per iteration less."""
         self.proj_mat.T.apply(self.d_res, self.d_bp)                                    # sirt.py:61
-        be.mul(self.d_bp, self.d_V)                                                     # sirt.py:63 (sirt_mpi.py:101)
         self._allreduce_vol(self.d_bp)                                                  # sirt_mpi.py:102-103
 
     def run_main_iteration(self, niter=100, make_plot=False, projections=None, positivity=False, debug=False):

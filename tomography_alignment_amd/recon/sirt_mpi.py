@@ -133,13 +133,12 @@ class SIRT(_SIRT):
             return super(SIRT, self)._backproject_scaled()
         be, comm, plane = self.be, self.comm, self._plane
         self.d_bp.zero_()
-        for (xt0, xt1), (x_lo, x_hi), _ in self._plan:
+        for i, ((xt0, xt1), (x_lo, x_hi), _) in enumerate(self._plan):
             if self.my_n_proj > 0:
-                be.adjoint_xslab(self.proj_mat.poses, self.d_res, self.d_bp, xt0, xt1)
+                be.adjoint_xslab(self.proj_mat.poses, self.d_res, self.d_bp, xt0, xt1, same_sinogram=(i > 0))
             seg = self.d_bp.view(x_lo * plane, (x_hi - x_lo) * plane)
-            if x_hi > x_lo:
-                be.mul(seg, self.d_V.view(x_lo * plane, (x_hi - x_lo) * plane))
             comm.allreduce_sum_async(seg)           # issued for EVERY slab on every rank (an empty one too): same sequence everywhere
+                                                    # (the scaling by V -- sirt_mpi.py:101 -- commutes with the sum: applied by the update)
 
     def _update(self, positivity, last=False):
         if not self._iter_pipelined:
@@ -151,7 +150,7 @@ class SIRT(_SIRT):
         for i, (_, (x_lo, x_hi), (f0, f1)) in enumerate(self._plan):
             comm.wait_next()
             o, n = x_lo * plane, (x_hi - x_lo) * plane
-            be.update_acc(self.d_rec.view(o, n), self.d_bp.view(o, n), None, positivity,
+            be.update_acc(self.d_rec.view(o, n), self.d_bp.view(o, n), self.d_V.view(o, n), positivity,
                           self.d_gt.view(o, n) if self.d_gt is not None else None, first=(i == 0))
             if ahead and f1 > f0:
                 be.forward_xslab(self.proj_mat.poses, self.d_rec, self.d_ax, f0, f1)
