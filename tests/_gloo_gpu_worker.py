@@ -72,10 +72,12 @@ def main(out_path):
 
     ctx = _lib.Context(0)
     comm = HostStagedComm(ctx)
-    shape, ndet, n_proj = (80, 40, 48), (72, 56), 12            # 6 tile columns; ragged in every axis
+    # 6 tile columns, ragged in every axis; 200 planes = two 128-plane blocks of the flat forward / four 64-plane chunks of the gather
+    # back-projection, the object in planes 70 .. 149 only: all-zero images, empty sinogram planes and z chunks that end at once take part
+    shape, ndet, n_proj = (80, 40, 200), (72, 210), 12
     rng = np.random.default_rng(11)
     x = np.zeros(shape, np.float32)
-    x[10:70, 6:34, 8:40] = rng.uniform(0.2, 1.0, (60, 28, 32)).astype(np.float32)
+    x[10:70, 6:34, 70:150] = rng.uniform(0.2, 1.0, (60, 28, 80)).astype(np.float32)
     phi = np.linspace(0.05, np.pi - 0.05, n_proj)
     cor = np.zeros((n_proj, 3))
     cor[:, 0] = rng.uniform(-1, 1, n_proj)                       # per-angle COR shifts must follow their angles into the shards

@@ -241,10 +241,12 @@ def test_pipelined_allreduce_path_matches_plain(shepp32):
     # A ragged volume with 6 tile columns, flat and tilted poses, positivity and a ground truth (the error sum accumulates over the
     # slabs on the device); per iteration every slab's all-reduce is waited for once and iterations 2.. launch no whole forward.
     from oracle import oracle as orc
-    shape, ndet, n_proj = (80, 40, 48), (72, 56), 12
+    # (200 planes, the object in planes 70 .. 149: the flat forward's live-block lists, empty sinogram planes and the gather
+    #  back-projection's z chunks that end at once all take part in the slab calls)
+    shape, ndet, n_proj = (80, 40, 200), (72, 210), 12
     rng = np.random.default_rng(11)
     x = np.zeros(shape, np.float32)
-    x[10:70, 6:34, 8:40] = rng.uniform(0.2, 1.0, (60, 28, 32)).astype(np.float32)
+    x[10:70, 6:34, 70:150] = rng.uniform(0.2, 1.0, (60, 28, 80)).astype(np.float32)
     phi = np.linspace(0.05, np.pi - 0.05, n_proj)
     from tomography_alignment_amd.utilities.geometry import Geometry
     geo2 = Geometry(n_proj, np.array(shape), np.ones(3), np.array(ndet), np.ones(2))
