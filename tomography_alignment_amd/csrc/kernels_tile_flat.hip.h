@@ -542,7 +542,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
     if ((int)blockIdx.x >= list[0]) return;
     const int blk = list[1 + blockIdx.x];
     const int z0 = (blk % nzb) * (2 * FLZ), y0 = -1 + ((blk / nzb) % nty) * ATY, x0 = -1 + (blk / (nzb * nty) + tile_x0) * ATX;
-    const bool live[2] = {(flags[blk] & 1) != 0, (flags[blk] & 2) != 0};
+    (void)flags;        // (per-image flags: an all-zero image of a live block yields zero sums, which the row tail does not send)
     for (int e = threadIdx.x; e < ALX * ALY * FLZ * 2; e += FZ_WAVES * 64) {          // e = ((lx * ALY + ly) * FLZ + lz) * 2 + image
         const int k = e & 1, e1 = e >> 1;
         const int lz = e1 % FLZ, t2 = e1 / FLZ, ly = t2 % ALY, lx = t2 / ALY;
@@ -556,7 +556,6 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
     const int64_t orgx = (int64_t)x0 << 32, orgy = (int64_t)y0 << 32;
     const size_t n_det = (size_t)g.ndx * g.ndz;
     const float two_m32 = 2.3283064365386963e-10f;
-    const unsigned lane8 = (unsigned)lane * 8u;
     float4 *const tw = tab_w + wv * FT2_TAB_ALLOC;
     const lds_cfloat *const img_l = (const lds_cfloat *)img;            // explicit LDS pointer (address space 3): ds_read, not flat loads
 
@@ -564,20 +563,24 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
         const AdjC &c = pcs[ip];
         const int p0z_i = (int)(c.fp0[2] >> 32);
         const float wcz = (float)(unsigned)c.fp0[2] * two_m32, wfz = 1.f - wcz;
-        bool zuse[2], ray_ok[2];
-        const int izb = z0 - p0z_i;                                    // the ray whose lower plane is image 0's plane 0
-        const int iz0 = izb + lane;                                    // this lane's ray in image 0; + FLZ in image 1
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int izoff = izb + k * FLZ;
-            // image 0's last ray has image 1's plane 0 above it: image 0 is written whenever EITHER image holds a non-zero voxel
-            zuse[k] = (live[k] || (k == 0 && live[1])) && !(izoff + FLZ <= 0 || izoff >= g.ndz);
-            const int iz = iz0 + k * FLZ;
-            ray_ok[k] = zuse[k] && iz >= 0 && iz < g.ndz;
-        }
-        // the ray BELOW image 0's first (its upper plane is this work-group's plane 0, its lower one the previous work-group's last)
-        const bool low_ray = live[0] && wcz != 0.f && izb - 1 >= 0 && izb - 1 < g.ndz;
-        if (!(zuse[0] || zuse[1] || low_ray)) continue;
+        // Rays and lanes.  The work-group's planes z0 .. z0 + 127 give to the rays izb - 1 .. izb + 127 (izb = z0 - floor(p0z): the ray whose lower
+        // plane is plane 0; the ray below it only when the z fraction w_c is not 0).  The row's sums go out as up to THREE atomic instructions
+        // over the 64-ray windows that start at w0 = the multiple of 16 at or below the first of those rays, so every instruction is 64-B
+        // aligned whatever the projection's z offset (64-B units are what the memory side prices, header).  To that end lane L holds plane
+        // (L - t) mod 64 of both images, t = izb - w0 in 0 .. 16: the sums arrive already rotated into window order -- window 0 = lanes >= t of
+        // image 0 (+ the ray below in lane t - 1), window 1 = lanes < t of image 0 (its top planes) and lanes >= t of image 1, window 2 =
+        // lanes < t of image 1.  t = 0 in the nominal geometry: two full windows, as before.
+        const int izb = z0 - p0z_i;
+        const bool lerp = wcz != 0.f;
+        const int w0 = (lerp ? izb - 1 : izb) & ~15;                   // (two's complement: floors negative rays too)
+        const int t = izb - w0;
+        const int lane_wrap = (t - 1) & 63;                             // the lane that holds plane 63 of an image
+        const unsigned lane8 = (unsigned)((lane - t) & 63) * 8u;
+        const int ray0 = w0 + lane;                                     // this lane's ray in window 0; + 64, + 128 in windows 1, 2
+        const bool m0 = (lane >= t || (lerp && lane == t - 1)) && ray0 >= 0 && ray0 < g.ndz;
+        const bool m1 = ray0 + 64 >= 0 && ray0 + 64 < g.ndz;
+        const bool m2 = lane < t && ray0 + 128 >= 0 && ray0 + 128 < g.ndz;
+        if (!__builtin_amdgcn_ballot_w64(m0 || m1 || m2)) continue;     // none of its rays is on the detector
         const float qx = bcx - (float)c.p0[0], qy = bcy - (float)c.p0[1];
         const float m00 = (float)c.minv[0][0], m01 = (float)c.minv[0][1];
         const float ixc = m00 * qx + m01 * qy;
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
         int64_t k_fux = c.fu[0], k_fuy = c.fu[1], k_fdx = c.fd[0], k_fdy = c.fd[1];
         asm volatile("" : "+v"(ldx), "+v"(ldy));                       // see k_tile_flat: keep the row loop's inputs in registers
         asm volatile("" : "+s"(k_fux), "+s"(k_fuy), "+s"(k_fdx), "+s"(k_fdy));
-        float *const proj_c = proj + (size_t)c.slot * n_det + iz0;
+        float *const proj_c = proj + (size_t)c.slot * n_det + ray0;
 
         for (int r0 = 0; r0 < n_rows_w; r0 += 64) {
             int v_jlo, v_jhi;
@@ -692,33 +695,24 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
 #undef FT2_W
                 }
                 const f32x2 Pt = Pa + Pb;
-                const float S[2] = {Pt.x, Pt.y};
-                if (low_ray) {                                                 // wave-uniform; never taken in the nominal geometry (w_c = 0)
-                    const float vlo = wcz * S[0];
-                    if (lane == 0 && vlo != 0.f) atomicAdd(pr - 1, vlo);       // pr points at this lane's ray of image 0: lane 0's is ray izb
-                }
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    if (!zuse[k]) continue;
-                    // plane lane + 1 by a DPP wave shift (a VALU move; __shfl_down is a ds_bpermute_b32: an LDS round trip per row and image);
-                    // lane 63 receives 0 (bound_ctrl) -- image 0's lane 63 then takes image 1's plane 0, image 1's lane 63 keeps 0: that
-                    // plane belongs to the next work-group in z (see low_ray there)
-                    float Sp1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(S[k]), 0x130, 0xf, 0xf, true));
-                    if (k == 0) Sp1 = lane == 63 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S[1]), 0)) : Sp1;
-                    const float val = wfz * S[k] + wcz * Sp1;
-                    // the float atomics are this kernel's tightest bound (see the header) and are priced per 64-B unit touched: lanes whose
-                    // value is 0 (rays that crossed only zero voxels of a live tile) do not take part, a row of zeros issues nothing
-                    const bool add = ray_ok[k] && val != 0.f;          // (an empty mask skips the instruction: s_cbranch_execz)
-#ifdef TOMO_ABLATE_FWD_ATOMICS          // measurement builds only (tools/gpu_r3l.sh): what the kernel costs without its atomics / with plain stores
-#if TOMO_ABLATE_FWD_ATOMICS == 2
-                    if (add) pr[k * FLZ] = val;
+                const float s0 = Pt.x, s1 = Pt.y;                              // image 0 / image 1, plane (lane - t) mod 64
+                // the plane above: the next lane's (DPP wave rotate: a VALU move, not a ds_bpermute round trip) -- except above plane 63, where
+                // it is the next image's plane 0 (image 1's for image 0; the next work-group's for image 1: that one adds its share itself,
+                // as this one does for the ray below its plane 0 in window 0's lane t - 1)
+                const float r0n = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0x134, 0xf, 0xf, false));       // wave_rol:1: lane l <- lane l + 1, lane 63 <- lane 0
+                const float r1n = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x134, 0xf, 0xf, false));
+                const bool wrap = lane == lane_wrap;
+                const float val0 = wfz * s0 + wcz * (wrap ? r1n : r0n);
+                const float val1 = wfz * s1 + wcz * (wrap ? 0.f : r1n);
+                // lanes whose value is 0 (rays that crossed only zero voxels, all-zero images) do not take part; an empty mask skips the instruction
+                const float o0 = lane >= t ? val0 : wcz * r0n, o1 = lane < t ? val0 : val1;
+#ifdef TOMO_ABLATE_FWD_ATOMICS          // measurement builds only (tools/gpu_r3l.sh): what the kernel costs without its atomics
+                asm volatile("" :: "v"(o0), "v"(o1), "v"(val1));
 #else
-                    asm volatile("" :: "v"(val));
+                if (m0 && o0 != 0.f) atomicAdd(pr, o0);
+                if (m1 && o1 != 0.f) atomicAdd(pr + 64, o1);
+                if (m2 && val1 != 0.f) atomicAdd(pr + 128, val1);
 #endif
-#else
-                    if (add) atomicAdd(pr + k * FLZ, val);
-#endif
-                }
             }
         }
     }

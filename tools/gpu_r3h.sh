@@ -7,4 +7,4 @@ timeout -k 10 300 python3 -m pytest tests/test_gpu_parity.py -m gpu -q -k "flat"
 rc=$?
 echo "pytest rc=$rc"; grep -E "passed|failed|FAILED|Error" $R/gpurun_out/r3h_pytest.log | tail -5
 if [ $rc -ne 0 ]; then tail -40 $R/gpurun_out/r3h_pytest.log; exit $rc; fi
-timeout -k 10 300 python3 tools/quick_bench.py fwd:1024:128:tilt=0:fwd_flat_tab=0 fwd:1024:128:tilt=0:fwd_flat_tab=1 fwd:1024:128:tilt=0:fwd_flat_tab=0:shepp=1 fwd:1024:128:tilt=0:fwd_flat_tab=1:shepp=1 fwd:512:128:tilt=0:fwd_flat_tab=0 fwd:512:128:tilt=0:fwd_flat_tab=1 fwd:1024:1024:tilt=0 fwd:1024:1024:tilt=0:shepp=2 fwd:1024:1024:tilt=0:shepp=1 2>&1 | tee $R/gpurun_out/r3h_time.log
+timeout -k 10 300 python3 tools/quick_bench.py fwd:1024:128:tilt=0:fwd_flat_tab=0 fwd:1024:128:tilt=0:fwd_flat_tab=1 fwd:1024:128:tilt=0:fwd_flat_tab=0:shepp=1 fwd:1024:128:tilt=0:fwd_flat_tab=1:shepp=1 fwd:512:128:tilt=0:fwd_flat_tab=0 fwd:512:128:tilt=0:fwd_flat_tab=1 fwd:1024:1024:tilt=0 fwd:1024:1024:tilt=0:shift=1 fwd:1024:1024:tilt=0:shepp=2 2>&1 | tee $R/gpurun_out/r3h_time.log

@@ -15,9 +15,12 @@ from tomography_alignment_amd.backend import HipBackend  # noqa: E402
 from tomography_alignment_amd.utilities.geometry import Geometry  # noqa: E402
 
 
-def poses(n_proj, tilt, rng):
+def poses(n_proj, tilt, rng, shift=False):
     phi = np.linspace(0, np.pi, n_proj)
-    if tilt:
+    if shift:                           # untilted, translated: tx, tz ~ U(+-2 px) -- the flat kernels with fractional z offsets per projection
+        a = np.zeros(n_proj); b = np.zeros(n_proj)
+        xyz = np.zeros((n_proj, 3)); xyz[:, 0] = rng.uniform(-2, 2, n_proj); xyz[:, 2] = rng.uniform(-2, 2, n_proj)
+    elif tilt:
         a = np.deg2rad(rng.uniform(-tilt, tilt, n_proj)); b = np.deg2rad(rng.uniform(-tilt, tilt, n_proj))     # tilt = half-range in degrees
         xyz = np.zeros((n_proj, 3)); xyz[:, 0] = rng.uniform(-2, 2, n_proj); xyz[:, 2] = rng.uniform(-2, 2, n_proj)
     else:
@@ -25,7 +28,7 @@ def poses(n_proj, tilt, rng):
     return _lib.poses_array(phi, a, b, xyz, np.zeros(3))
 
 
-def run(N, n_proj, what, tilt=True, reps=2, opts=None, shepp=False, nz=None):
+def run(N, n_proj, what, tilt=True, reps=2, opts=None, shepp=False, nz=None, shift=False):
     rng = np.random.default_rng(0)
     nz = nz or N
     geo = Geometry(n_proj, np.array([N, N, nz]), np.ones(3), np.array([N, nz]), np.ones(2))
@@ -44,7 +47,7 @@ def run(N, n_proj, what, tilt=True, reps=2, opts=None, shepp=False, nz=None):
         from tomography_alignment_amd.utilities.generate_phantom import SHEPP_LOGAN
         be.phantom(vol, (N, N, N), SHEPP_LOGAN)
     prj = be.zeros(n_proj * N * nz); be.fill(prj, 1.0)
-    P = poses(n_proj, tilt, rng)
+    P = poses(n_proj, tilt, rng, shift)
     grad = be.empty(6 * N * N) if what == "pg" else None
     fn = {"fwd": lambda: be.forward(P, vol, prj), "adj": lambda: be.adjoint(P, prj, vol),
           "bpv": lambda: be.backproject_voxel(P, prj, vol),
@@ -70,7 +73,7 @@ if __name__ == "__main__":
         opts = {}
         for kv in parts[3:]:
             k, v = kv.split("=")
-            if k in ("tilt", "shepp", "nz"):
+            if k in ("tilt", "shepp", "nz", "shift"):
                 continue
             opts[k] = int(v)
         tilt = 1.0
@@ -78,4 +81,4 @@ if __name__ == "__main__":
             if kv.startswith("tilt="):
                 tilt = float(kv[5:])
         run(N, n_proj, what, tilt=tilt, opts=opts, shepp=max([int(kv[6:]) for kv in parts[3:] if kv.startswith('shepp=')] or [0]),
-            nz=max([int(kv[3:]) for kv in parts[3:] if kv.startswith('nz=')] or [0]) or None)
+            nz=max([int(kv[3:]) for kv in parts[3:] if kv.startswith('nz=')] or [0]) or None, shift=any(kv == 'shift=1' for kv in parts[3:]))
