@@ -81,10 +81,28 @@ __global__ __launch_bounds__(1024) void k_zflags_prefix(const unsigned char *__r
     if (threadIdx.x == 0) cum[n] = base;
 }
 
+// How the 64-plane z chunks are grouped into work-groups of GWAVES: *shift = (GWAVES - first live chunk mod GWAVES) mod GWAVES, so that the
+// first chunk that can receive anything starts a work-group (work-group q holds chunks q * GWAVES - shift ...).  With the chunks grouped from 0
+// a live range that starts mid-group leaves a work-group with dead waves at each end; its live waves then compute the dead ones' share of the
+// weight tables.  A chunk c is live when a flagged sinogram plane lies in [64 c - zc_hi - 1, 64 c + 63 - zc_lo] (as in the kernel).
+__global__ __launch_bounds__(64) void k_zchunk_shift(const unsigned char *__restrict__ flags, int ndz, int nz, int zc_lo, int zc_hi, int *__restrict__ shift)
+{
+    const int n_chunk = (nz + 63) / 64;
+    int first = n_chunk;
+    for (int c = threadIdx.x; c < n_chunk; c += 64) {
+        bool any = false;
+        for (int i = max(0, 64 * c - zc_hi - 1); i <= min(ndz - 1, 64 * c + 63 - zc_lo) && !any; ++i) any = flags[i] != 0;
+        if (any) first = min(first, c);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+    if (threadIdx.x == 0) *shift = first >= n_chunk ? 0 : (GWAVES - first % GWAVES) % GWAVES;
+}
+
 template <int NJ>      // samples per row that can reach a column: 3 for step >= 0.95 voxel, 6 for step >= 0.475
 __global__ __launch_bounds__(GWAVES * 64, 16 / GWAVES) void k_adj_gather_flat(const GfC *__restrict__ cs, int n_proj, const float *__restrict__ proj,
                                                                  float *__restrict__ vol, TomoGeomC g, int xs, int xe, int patched,
-                                                                 const unsigned char *__restrict__ zflags, int zc_lo, int zc_hi)
+                                                                 const unsigned char *__restrict__ zflags, int zc_lo, int zc_hi, const int *__restrict__ zshift)
 {
     __shared__ __attribute__((aligned(16))) float rows[GWAVES][GROWS * GPITCH];
     __shared__ float4 wtab[3][GWAVES][64];          // [group mod 3][projection of the group][column] = (i0, W0, W1, W2)
@@ -99,7 +117,8 @@ __global__ __launch_bounds__(GWAVES * 64, 16 / GWAVES) void k_adj_gather_flat(co
     // (Small grids keep the plain order, patched = 0: the patch grid is padded to 8 x 96 work-groups, which costs more than
     // the reuse gains below ~256 patches.  Measured at 1024^3: same speed; fabric traffic -64 % on a 64-angle launch, -15 %
     // (0.89 -> 0.76 TB) over 1024 angles, where the work-groups of a patch drift apart in angle index.)
-    const int ntx = (xe - xs + GTX - 1) / GTX, nty = (g.ny + GTY - 1) / GTY, nzq = (g.nz + 64 * GWAVES - 1) / (64 * GWAVES);
+    const int ntx = (xe - xs + GTX - 1) / GTX, nty = (g.ny + GTY - 1) / GTY, nzq = (g.nz + 64 * GWAVES - 1) / (64 * GWAVES) + 1;
+    // (+ 1: the chunks are grouped from -shift, k_zchunk_shift above; with shift = 0 the last layer of work-groups lies past the volume and ends at once)
     int tx, ty, zq;
     if (patched) {
         const int npx = (ntx + GPX - 1) / GPX, npy = (nty + GPY - 1) / GPY;
@@ -113,11 +132,11 @@ __global__ __launch_bounds__(GWAVES * 64, 16 / GWAVES) void k_adj_gather_flat(co
         ty = (int)((blockIdx.x / (unsigned)nzq) % (unsigned)nty);
         tx = (int)(blockIdx.x / ((unsigned)nzq * (unsigned)nty));
     }
-    const int x0 = xs + tx * GTX, y0 = ty * GTY, z0 = (zq * GWAVES + wv) * 64;
+    const int x0 = xs + tx * GTX, y0 = ty * GTY, z0 = (zq * GWAVES + wv - *zshift) * 64;
     if (tx >= ntx || ty >= nty || zq >= nzq) return;                    // uniform over the WORK-GROUP (barriers below)
     // a wave past the volume still computes its share of tables; so does one whose 64 planes Z can only receive zeros: plane Z gathers from the
     // sinogram planes Z - zc and Z - zc - 1 (zc in [zc_lo, zc_hi] over the projections), and k_sino_zflags marked the planes that hold anything
-    bool zlive = z0 < g.nz;
+    bool zlive = z0 >= 0 && z0 < g.nz;
     if (zlive) {
         bool any = false;
         for (int i = z0 - zc_hi - 1 + lane; i <= z0 + 63 - zc_lo; i += 64) any |= i >= 0 && i < g.ndz && zflags[i] != 0;

@@ -60,7 +60,7 @@ struct tomo_ctx {
     int reuse_sino_flags = 0;           // option: the caller vouches the sinogram of the previous back-projection call is unchanged
     const void *zf_src = nullptr;       // sinogram whose plane flags (+ prefix counts when zf_has_cum) d_blk currently holds; nullptr: none
     int zf_nproj = 0;
-    bool zf_has_cum = false;
+    bool zf_has_cum = false, zf_has_shift = false;
     size_t fwd_blk_flat_ints = 0;       // ints of d_blk the flat forward of the current call uses (the general kernel's tile list follows)
     // general float workspace (grow-only): the TV-FISTA proximal step keeps its 7 fields here across calls
     float *d_ws = nullptr;

@@ -381,26 +381,32 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
     // planes skips its loads and its plane loop (zlive), the general kernel skips a (tile, projection) whose rays all lie in such planes
     // (zcum: prefix counts of the flags).  One coalesced pass over the sinogram (0.8 ms for 4.3 GB); flags and counts live in d_blk.
     unsigned char *d_zf = nullptr;
-    int *d_zcum = nullptr;
+    int *d_zcum = nullptr, *d_zshift = nullptr;
     if (n_gather > 0 || n_proj > n_flat) {
         const size_t zf_ints = ((size_t)g.ndz + 3) / 4;
         const size_t n_tile_all = (size_t)grid.x * grid.y * grid.z;
-        rc = tomo_ensure_blk(ctx, zf_ints + (size_t)g.ndz + 1 + (n_proj > n_flat ? 1 + n_tile_all + (n_tile_all + 3) / 4 : 0));
+        rc = tomo_ensure_blk(ctx, zf_ints + (size_t)g.ndz + 2 + (n_proj > n_flat ? 1 + n_tile_all + (n_tile_all + 3) / 4 : 0));
         if (rc) return rc;
         d_zf = (unsigned char *)ctx->d_blk;
         d_zcum = ctx->d_blk + zf_ints;
+        d_zshift = d_zcum + g.ndz + 1;
         const bool want_cum = n_proj > n_flat;
         // (option "reuse_sino_flags": the x-slab calls of one back-projection pass scan the sinogram once, not once per slab)
-        const bool cached = ctx->reuse_sino_flags && ctx->zf_src == (const void *)d_proj && ctx->zf_nproj == n_proj && (ctx->zf_has_cum || !want_cum);
+        const bool cached = ctx->reuse_sino_flags && ctx->zf_src == (const void *)d_proj && ctx->zf_nproj == n_proj && (ctx->zf_has_cum || !want_cum) &&
+                            (ctx->zf_has_shift || n_gather == 0);
         if (!cached) {
             TOMO_HIP(ctx, hipMemsetAsync(d_zf, 0, (size_t)g.ndz, ctx->stream));
             const long long n_rows = (long long)n_proj * g.ndx;
             const unsigned gy = (unsigned)std::min<long long>(n_rows, 4096);
             TOMO_LAUNCH(ctx, "k_sino_zflags", k_sino_zflags, dim3((unsigned)((g.ndz + 255) / 256), gy), dim3(256), 0, d_proj, n_rows, g.ndz, d_zf);
             if (want_cum) TOMO_LAUNCH(ctx, "k_sino_zflags", k_zflags_prefix, dim3(1), dim3(1024), 0, (const unsigned char *)d_zf, g.ndz, d_zcum);
+            if (n_gather > 0)
+                TOMO_LAUNCH(ctx, "k_sino_zflags", k_zchunk_shift, dim3(1), dim3(64), 0, (const unsigned char *)d_zf, g.ndz, g.nz, ctx->tile_cache_zc_lo,
+                            ctx->tile_cache_zc_hi, d_zshift);
             ctx->zf_src = (const void *)d_proj;
             ctx->zf_nproj = n_proj;
             ctx->zf_has_cum = want_cum;
+            ctx->zf_has_shift = n_gather > 0;
         }
     }
     if (n_gather > 0) {
@@ -408,7 +414,7 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
         const int xs = std::max(0, ATX * xt0 - 1), xe = (xt1 == n_xt) ? g.nx : std::min(g.nx, ATX * xt1 - 1);
         if (xe > xs) {
             // one-dimensional grid of patches (see the kernel): ceil(#patches / 8) groups of 8 patches x GPX*GPY tiles
-            const int ntx = (xe - xs + GTX - 1) / GTX, nty = (g.ny + GTY - 1) / GTY, nzq = (g.nz + 64 * GWAVES - 1) / (64 * GWAVES);
+            const int ntx = (xe - xs + GTX - 1) / GTX, nty = (g.ny + GTY - 1) / GTY, nzq = (g.nz + 64 * GWAVES - 1) / (64 * GWAVES) + 1;   // + 1: see the kernel
             const long long n_patch = (long long)nzq * ((ntx + GPX - 1) / GPX) * ((nty + GPY - 1) / GPY);
             const int patched = n_patch >= 64 ? 1 : 0;       // (256 until round 3: the sharded solver's x slabs -- 88 .. 176 patches at 1024^3 -- ran unpatched, 10 % slower)
             const long long n_wg = patched ? ((n_patch + 7) / 8) * 8 * (GPX * GPY) : (long long)nzq * ntx * nty;
@@ -417,10 +423,10 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
             const int zc_lo = ctx->tile_cache_zc_lo, zc_hi = ctx->tile_cache_zc_hi;
             if (ctx->tile_cache_eb_max < 1.49)
                 TOMO_LAUNCH(ctx, "k_adj_gather_flat", k_adj_gather_flat<3>, ggrid, dim3(GWAVES * 64), 0, d_gfc, n_gather, d_proj, d_vol, g, xs, xe, patched,
-                            (const unsigned char *)d_zf, zc_lo, zc_hi);
+                            (const unsigned char *)d_zf, zc_lo, zc_hi, (const int *)d_zshift);
             else        // finer sampling along the rays (step down to ~0.475 voxel): six samples per row can reach a column
                 TOMO_LAUNCH(ctx, "k_adj_gather_flat", k_adj_gather_flat<6>, ggrid, dim3(GWAVES * 64), 0, d_gfc, n_gather, d_proj, d_vol, g, xs, xe, patched,
-                            (const unsigned char *)d_zf, zc_lo, zc_hi);
+                            (const unsigned char *)d_zf, zc_lo, zc_hi, (const int *)d_zshift);
         }
     }
     if (n_proj == n_gather) return TOMO_OK;
@@ -441,7 +447,7 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
         // sit behind the plane flags and their prefix counts in d_blk
         const size_t n_tile = (size_t)grid.x * grid.y * grid.z;
         if (n_tile >= (size_t)1 << 30) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_adjoint: volume too large for the tile list");
-        const size_t head = ((size_t)g.ndz + 3) / 4 + (size_t)g.ndz + 1;
+        const size_t head = ((size_t)g.ndz + 3) / 4 + (size_t)g.ndz + 2;
         rc = tomo_ensure_blk(ctx, head + 1 + n_tile + (n_tile + 3) / 4);      // (grows at most once per geometry: d_zf / d_zcum are re-derived below)
         if (rc) return rc;
         if ((unsigned char *)ctx->d_blk != d_zf) return tomo_fail(ctx, TOMO_ERR_STATE, "tomo_adjoint: block buffer moved");
