@@ -190,6 +190,67 @@ def test_gradient_kernels_agree_on_random_geometry(seed):
     print("worst: per ray between kernels %.2e, per ray vs oracle (well-conditioned rays) %.2e, fused sums vs own rays %.2e" % (worst_ray, worst_orc, worst_sum))
 
 
+def test_gradient_cancellation_regression_59x71x61_detector_21x5():
+    """Named regression (profiles/round4_grad_error_model.md): the one geometry on which the round-3 soak
+    saw the gradient kernels leave 1e-5 of the float64 oracle (seed 81: 1.06e-5 / 1.19e-5 on the translation rows of pose 1, every
+    variant alike).  Smooth 59 x 71 x 61 volume, 21 x 5 detector, phi ~ pi/2: the per-sample gradients of a ray cancel to 1e-4 of their
+    sum of magnitudes along the beam and the translation rows' maximum over the 105 rays is 0.05 -- float32 rounding at the size of
+    the voxel VALUES (lerp two values, then subtract; 32-sample float32 partial sums) was 1e-5 of that.  Round 4: lerps on the corners
+    relative to corner 000 and two-level sums (csrc/kernels_grad.hip.h, GRAD ACCURACY); tools/grad_error_model.py reproduces both
+    figures on the CPU (1.06e-5 -> 4.8e-6).  Every variant, per ray and fused, at the test-wide bar; the margin is asserted too
+    (7e-6) so that a regression towards the old arithmetic shows before it crosses the bar.  Values as hex floats."""
+    from oracle import oracle as orc
+    from tomography_alignment_amd import _lib
+    from tomography_alignment_amd.utilities.geometry import Geometry
+    from tomography_alignment_amd.utilities.projection_operators import ProjectionMatrix
+    H = float.fromhex
+    shape, ndet, step, n = (59, 71, 61), (21, 5), 1.0, 2
+    phi = np.array([H("0x1.777fa90d09e5bp+0"), H("0x1.8f1cb87a4d8b3p+0")])
+    alpha = np.array([H("0x1.94c349709e9f8p-8"), H("0x1.502da7ea00ae0p-10")])
+    beta = np.array([H("0x1.2a268c8b363f4p-9"), H("0x1.1c629dc1be11ep-8")])
+    xyz = np.array([[H("-0x1.857d5177751c2p+1"), H("0x1.326389897c4e0p+1"), H("0x1.91f04b0b6c07cp+0")],
+                    [H("-0x1.7a3a494433ba0p-2"), H("-0x1.c15447448c600p+0"), H("-0x1.251ccacee4d2ep+1")]])
+    cor = np.zeros((n, 3))
+    cor[:, 0] = [H("0x1.35053e86ec116p-1"), H("0x1.68acc151c2b4ep-1")]
+    fr = [H("0x1.b95feefb84278p-3"), H("0x1.7c5677f7d36eap-3"), H("0x1.021966b87e1ebp-2")]
+    ph = [H("0x1.58259c296fb8bp+2"), H("0x1.1cb4112eccb74p-1"), H("0x1.81db66af4abeap+2")]
+    geo = Geometry(n, np.array(shape), np.ones(3), np.array(ndet), np.ones(2), cor_shift=cor, step_size=step)
+    og = orc.Geo(n, np.array(shape), np.ones(3), np.array(ndet), np.ones(2), cor_shift=cor, step_size=step)
+    ii, jj, kk = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), np.arange(shape[2]), indexing="ij")
+    x = (0.6 + 0.4 * np.cos(fr[0] * ii + ph[0]) * np.cos(fr[1] * jj + ph[1]) * np.cos(fr[2] * kk + ph[2])).astype(np.float32)
+    n_det = ndet[0] * ndet[1]
+    poses = _lib.poses_array(phi, alpha, beta, xyz, cor)
+    P = ProjectionMatrix(geo)
+    be = P.backend
+    d_x = be.upload(x)
+    worst = {}
+    for i in range(n):
+        want_p, want_g = orc.projection_gradient(og, x, alpha[i], beta[i], phi[i], xyz[i], cor[i], precision=np.float64)
+        well = orc.ray_face_distance(og, alpha[i], beta[i], phi[i], xyz[i], cor[i]) >= 2e-5
+        assert well.sum() >= n_det - 2                 # not a cell-face case: (nearly) every ray is compared
+        gmax = [np.max(np.abs(want_g[:3]))] * 3 + [np.max(np.abs(want_g[3:]))] * 3
+        b = (want_p + 0.05 * np.max(np.abs(want_p))).astype(np.float32)
+        res = b.astype(np.float64) - want_p
+        want_sum = -want_g @ res
+        size = np.abs(want_g) @ np.abs(res)
+        size = np.array([size[:3].max()] * 3 + [size[3:].max()] * 3)
+        d_b = be.upload(b)
+        for v in (1, 2, 3, 4):
+            be.ctx.set_option("grad_variant", v)
+            pr, gd = be.empty(n_det), be.empty(6 * n_det)
+            be.proj_grad(poses[i:i + 1], d_x, pr, gd)
+            p, g = pr.download().astype(np.float64), gd.download().reshape(6, n_det).astype(np.float64)
+            ev = rel_max(p, want_p)
+            eg = max(float(np.max(np.abs(g[r] - want_g[r])[well])) / gmax[r] for r in range(6))
+            cost, g6 = be.cost_grad(poses[i:i + 1], d_x, d_b)
+            es = float(np.max(np.abs(g6[0] - want_sum) / size))
+            worst[(i, v)] = (ev, eg, es)
+            assert ev < 1e-5 and eg < 7e-6 and es < 1e-5, ("pose", i, "variant", v, ev, eg, es)
+    be.ctx.set_option("grad_variant", 4)
+    print("59x71x61 / 21x5 regression, (pose, variant): (value, per-ray gradient, fused sums) rel-max: "
+          + "; ".join("%s: %.1e %.1e %.1e" % (k, *v) for k, v in sorted(worst.items())))
+
+
 def test_samples_per_ray_regression_54x18x27():
     """Named regression (VERDICT r2 #4 / DESIGN.md section 2): n = int(|r0| / step) (utilities/ray_voxel_utilities.py:88).  On a volume
     longer in x than in y the last sample of an oblique ray lies INSIDE the object, so n = K - 1 against K changes projections by a

@@ -90,13 +90,26 @@ __device__ __forceinline__ void grad_finish(const GradC &gc, const TomoGeomC &g,
 // Jacobian is applied once (same algebra as src/ray_wt_grad.f90:136-149).
 // FUSED: multiply by the residual and reduce to 7 numbers per projection.
 // ------------------------------------------------------------------------------------------------
-template <bool FUSED>
+// GRAD ACCURACY (round 4; tools/grad_error_model.py, profiles/round4_grad_error_model.md).  The pose gradient is a sum over a ray of
+// spatial gradients that largely cancel (along the beam the sum telescopes: sum_j|g_j| / |sum_j g_j| reached 1e4 on the round-3 soak
+// failure, a smooth 59 x 71 x 61 volume with a 21 x 5 detector), so float32 rounding AT THE SIZE OF THE VOXEL VALUES in the per-sample
+// gradient (a difference of two lerped values: 6e-8 x |v| per sample) and float32 partial sums of 32 samples showed as 1.06e-5 of
+// the row-group maximum -- the sample positions (1e-6 voxel) contribute 5e-7 and were not it.  All three kernels therefore
+//   * lerp the corners MINUS corner 000 (two packed subtractions and one add per sample): every rounding then scales with the local
+//     differences; the value is v000 + lerp(differences);
+//   * accumulate the seven sums in two float32 levels: TOMO_JS samples, then the block of TOMO_JB, then float64.
+// Model and GPU agree on the failing geometry (1.06e-5 before, 4.8e-6 after); the remaining error is the float32 rounding of the terms.
+#define TOMO_JS 8
+// PREC (option grad_v1_prec, a diagnostic of WHERE float32 costs accuracy; 0 = the production arithmetic): bit 0 = sample positions,
+// cells and fractions in float64 (no float32 in-block offsets), bit 1 = lerps and per-block sums in float64.
+template <bool FUSED, int PREC = 0>
 __global__ __launch_bounds__(256) void k_proj_grad(const ProjC *__restrict__ pcs, const GradC *__restrict__ gcs,
                                                    const float *__restrict__ vp, float *__restrict__ proj,
                                                    float *__restrict__ grad, const float *__restrict__ bvec,
                                                    float *__restrict__ resid, double *__restrict__ red, TomoGeomC g,
                                                    int row_order)
 {
+    typedef typename std::conditional<(PREC & 2) != 0, double, float>::type T;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ix = blockIdx.y * 4 + wv, ip = blockIdx.z;
     int iz = blockIdx.x * 64 + lane;
@@ -109,7 +122,7 @@ __global__ __launch_bounds__(256) void k_proj_grad(const ProjC *__restrict__ pcs
     ray_setup(c, g, ixc, iz, valid, r, staged_box(vp, g));
     const float dxf = (float)r.d[0], dyf = (float)r.d[1], dzf = (float)r.d[2];
     const int64_t sy = g.nzp, sx = (int64_t)g.nyp * g.nzp;
-    const float sfs = (float)(g.step / c.rlen);      // sf_j = (j*step)/|r_0|   ray_voxel_utilities.py:151
+    const T sfs = (T)(g.step / c.rlen);      // sf_j = (j*step)/|r_0|   ray_voxel_utilities.py:151
     double val = 0.0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
     for (int jb = r.j0; jb < r.j1; jb += TOMO_JB) {
         int ia[3];
@@ -117,27 +130,43 @@ __global__ __launch_bounds__(256) void k_proj_grad(const ProjC *__restrict__ pcs
         tomo_block_anchor(r.b, r.d, jb, ia, f0);
         const float *base = vp + ((int64_t)(ia[0] + TOMO_HALO) * sx + (int64_t)(ia[1] + TOMO_HALO) * sy + (ia[2] + TOMO_HALO));
         const int cnt = min(TOMO_JB, r.j1 - jb);
-        float av = 0.f, a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
-        for (int jj = 0; jj < cnt; ++jj) {
-            const float t = (float)jj;
-            const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
-            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-            const float wx = x - fx, wy = y - fy, wz = z - fz;
-            const float *q = base + ((int64_t)(int)fx * sx + (int64_t)(int)fy * sy + (int)fz);
-            const float v000 = q[0], v001 = q[1], v010 = q[sy], v011 = q[sy + 1];
-            const float v100 = q[sx], v101 = q[sx + 1], v110 = q[sx + sy], v111 = q[sx + sy + 1];
-            const float d00 = v001 - v000, d01 = v011 - v010, d10 = v101 - v100, d11 = v111 - v110;
-            const float c00 = fmaf(wz, d00, v000), c01 = fmaf(wz, d01, v010), c10 = fmaf(wz, d10, v100), c11 = fmaf(wz, d11, v110);
-            const float dz0 = fmaf(wy, d01 - d00, d00), dz1 = fmaf(wy, d11 - d10, d10);
-            const float gz = fmaf(wx, dz1 - dz0, dz0);
-            const float dy0 = c01 - c00, dy1 = c11 - c10;
-            const float e0 = fmaf(wy, dy0, c00), e1 = fmaf(wy, dy1, c10);
-            const float gy = fmaf(wx, dy1 - dy0, dy0);
-            const float gx = e1 - e0;
-            av += fmaf(wx, gx, e0);
-            const float sf = (float)(jb + jj) * sfs;
-            a0x += gx; a0y += gy; a0z += gz;
-            a1x = fmaf(sf, gx, a1x); a1y = fmaf(sf, gy, a1y); a1z = fmaf(sf, gz, a1z);
+        T av = 0, a0x = 0, a0y = 0, a0z = 0, a1x = 0, a1y = 0, a1z = 0;
+        for (int jq = 0; jq < cnt; jq += TOMO_JS) {          // two-level sums, see GRAD ACCURACY above
+            T qv = 0, q0x = 0, q0y = 0, q0z = 0, q1x = 0, q1y = 0, q1z = 0;
+            const int qe = min(jq + TOMO_JS, cnt);
+            for (int jj = jq; jj < qe; ++jj) {
+                T wx, wy, wz;
+                const float *q;
+                if (PREC & 1) {
+                    const double xd = r.b[0] + (double)(jb + jj) * r.d[0], yd = r.b[1] + (double)(jb + jj) * r.d[1], zd = r.b[2] + (double)(jb + jj) * r.d[2];
+                    const double fx = floor(xd), fy = floor(yd), fz = floor(zd);
+                    wx = (T)(xd - fx), wy = (T)(yd - fy), wz = (T)(zd - fz);
+                    q = vp + ((int64_t)((int)fx + TOMO_HALO) * sx + (int64_t)((int)fy + TOMO_HALO) * sy + ((int)fz + TOMO_HALO));
+                } else {
+                    const float t = (float)jj;
+                    const float x = fmaf(t, dxf, f0[0]), y = fmaf(t, dyf, f0[1]), z = fmaf(t, dzf, f0[2]);
+                    const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+                    wx = x - fx, wy = y - fy, wz = z - fz;
+                    q = base + ((int64_t)(int)fx * sx + (int64_t)(int)fy * sy + (int)fz);
+                }
+                // the corners relative to corner 000 (GRAD ACCURACY): every lerp below then rounds at the size of the local differences
+                const T v0 = q[0];
+                const T v001 = (T)q[1] - v0, v010 = (T)q[sy] - v0, v011 = (T)q[sy + 1] - v0;
+                const T v100 = (T)q[sx] - v0, v101 = (T)q[sx + 1] - v0, v110 = (T)q[sx + sy] - v0, v111 = (T)q[sx + sy + 1] - v0;
+                const T d00 = v001, d01 = v011 - v010, d10 = v101 - v100, d11 = v111 - v110;
+                const T c00 = wz * d00, c01 = fma(wz, d01, v010), c10 = fma(wz, d10, v100), c11 = fma(wz, d11, v110);
+                const T dz0 = fma(wy, d01 - d00, d00), dz1 = fma(wy, d11 - d10, d10);
+                const T gz = fma(wx, dz1 - dz0, dz0);
+                const T dy0 = c01 - c00, dy1 = c11 - c10;
+                const T e0 = fma(wy, dy0, c00), e1 = fma(wy, dy1, c10);
+                const T gy = fma(wx, dy1 - dy0, dy0);
+                const T gx = e1 - e0;
+                qv += v0 + fma(wx, gx, e0);
+                const T sf = (T)(jb + jj) * sfs;
+                q0x += gx; q0y += gy; q0z += gz;
+                q1x = fma(sf, gx, q1x); q1y = fma(sf, gy, q1y); q1z = fma(sf, gz, q1z);
+            }
+            av += qv; a0x += q0x; a0y += q0y; a0z += q0z; a1x += q1x; a1y += q1y; a1z += q1z;
         }
         val += (double)av;
         s0[0] += (double)a0x; s0[1] += (double)a0y; s0[2] += (double)a0z;
@@ -218,11 +247,15 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
         float av = 0.f;
         f32x2 a0xy = {0.f, 0.f}, a1xy = {0.f, 0.f}, az = {0.f, 0.f};              // (S0x, S0y), (S1x, S1y), (S0z, S1z)
         const float sfb = (float)jb * sfs;
+        for (int jq = lo; jq < hi; jq += TOMO_JS) {                               // two-level sums (GRAD ACCURACY)
+        float qv = 0.f;
+        f32x2 q0xy = {0.f, 0.f}, q1xy = {0.f, 0.f}, qz = {0.f, 0.f};
+        const int qe = min(jq + TOMO_JS, hi);
         // two samples per trip: all 16 gathers are issued before the first value is used (the kernel waits on memory 3/4 of
         // the time; this doubles the loads in flight per wave).  An odd tail re-reads sample A's address and is masked out.
-        for (int jj = lo; jj < hi; jj += 2) {
+        for (int jj = jq; jj < qe; jj += 2) {
             const float ta = (float)jj, tb = ta + 1.f;
-            const bool two = jj + 1 < hi;
+            const bool two = jj + 1 < qe;
             const float xa = fmaf(ta, dxf, f0[0]), ya = fmaf(ta, dyf, f0[1]), za = fmaf(ta, dzf, f0[2]);
             const float xb = fmaf(tb, dxf, f0[0]), yb = fmaf(tb, dyf, f0[1]), zb = fmaf(tb, dzf, f0[2]);
             const uint32_t voa = off0 + (uint32_t)__mul24(cvt_floor_i32(xa), (int)sx4) + (uint32_t)__mul24(cvt_floor_i32(ya), (int)sy4) + ((uint32_t)cvt_floor_i32(za) << 2);
@@ -239,36 +272,40 @@ __global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ 
             {
                 const float wx = fract_f32(xa), wy = fract_f32(ya), wz = fract_f32(za);
                 const f32x2 dy0 = a01 - a00, dy1 = a11 - a10;          // d/dy on the x = 0 / x = 1 faces, at z and z + 1
-                const f32x2 c0 = a00 + wy * dy0, c1 = a10 + wy * dy1;  // y-lerped
+                const f32x2 o00 = a00 - a00.x, o10 = a10 - a00.x;      // the corners relative to corner 000 (GRAD ACCURACY)
+                const f32x2 c0 = o00 + wy * dy0, c1 = o10 + wy * dy1;  // y-lerped
                 const f32x2 dx = c1 - c0;                              // d/dx at z, z + 1
                 const f32x2 e = c0 + wx * dx;                          // x,y-lerped value at z, z + 1
                 const f32x2 dyx = dy0 + wx * (dy1 - dy0);              // d/dy at z, z + 1
                 const float gz = e.y - e.x;
                 const float gx = fmaf(wz, dx.y - dx.x, dx.x), gy = fmaf(wz, dyx.y - dyx.x, dyx.x);
-                av += fmaf(wz, gz, e.x);
+                qv += a00.x + fmaf(wz, gz, e.x);
                 const float sf = fmaf(ta, sfs, sfb);                   // (jb + jj) * step / |r0|, one rounding
                 const f32x2 gxy = {gx, gy}, one_sf = {1.f, sf};
-                a0xy += gxy;
-                a1xy += sf * gxy;
-                az += one_sf * gz;
+                q0xy += gxy;
+                q1xy += sf * gxy;
+                qz += one_sf * gz;
             }
             {
                 const float keep = two ? 1.f : 0.f;
                 const float wx = fract_f32(xb), wy = fract_f32(yb), wz = fract_f32(zb);
                 const f32x2 dy0 = b01 - b00, dy1 = b11 - b10;
-                const f32x2 c0 = b00 + wy * dy0, c1 = b10 + wy * dy1;
+                const f32x2 o00 = b00 - b00.x, o10 = b10 - b00.x;
+                const f32x2 c0 = o00 + wy * dy0, c1 = o10 + wy * dy1;
                 const f32x2 dx = c1 - c0;
                 const f32x2 e = c0 + wx * dx;
                 const f32x2 dyx = dy0 + wx * (dy1 - dy0);
                 const float gz = keep * (e.y - e.x);
                 const float gx = keep * fmaf(wz, dx.y - dx.x, dx.x), gy = keep * fmaf(wz, dyx.y - dyx.x, dyx.x);
-                av = fmaf(keep, fmaf(wz, e.y - e.x, e.x), av);
+                qv = fmaf(keep, b00.x + fmaf(wz, e.y - e.x, e.x), qv);
                 const float sf = fmaf(tb, sfs, sfb);
                 const f32x2 gxy = {gx, gy}, one_sf = {1.f, sf};
-                a0xy += gxy;
-                a1xy += sf * gxy;
-                az += one_sf * gz;
+                q0xy += gxy;
+                q1xy += sf * gxy;
+                qz += one_sf * gz;
             }
+        }
+        av += qv; a0xy += q0xy; a1xy += q1xy; az += qz;
         }
         val += (double)av;
         s0[0] += (double)a0xy.x; s0[1] += (double)a0xy.y; s0[2] += (double)az.x;
@@ -395,7 +432,8 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
         const f32x2 up0 = {select_lanes2(n001, S##f001, S##fbm), select_lanes2(n101, S##f101, S##fbm)};                                  \
         const f32x2 up1 = {select_lanes2(n011, S##f011, S##fbm), select_lanes2(n111, S##f111, S##fbm)};                                  \
         const f32x2 d0 = up0 - lo0, d1 = up1 - lo1;                                  /* d/dz at y = 0, y = 1 */                    \
-        const f32x2 c0 = lo0 + S##wz * d0, c1 = lo1 + S##wz * d1;                    /* z-lerped corners */                        \
+        const f32x2 o0 = lo0 - S##v000, o1 = lo1 - S##v000;                          /* relative to corner 000 (GRAD ACCURACY) */  \
+        const f32x2 c0 = o0 + S##wz * d0, c1 = o1 + S##wz * d1;                      /* z-lerped corners */                        \
         const f32x2 dz = d0 + S##wy * (d1 - d0);                                                                                   \
         const f32x2 dy = c1 - c0;                                                                                                  \
         const f32x2 e = c0 + S##wy * dy;                                                                                           \
@@ -403,18 +441,23 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
         const float gz = fmaf(S##wx, dz.y - dz.x, dz.x);                                                                           \
         const float gy = fmaf(S##wx, dy.y - dy.x, dy.x);                                                                           \
         const float gx = e.y - e.x;                                                                                                \
-        av = fmaf(keep, fmaf(S##wx, gx, e.x), av);                                                                                 \
+        qv = fmaf(keep, S##v000 + fmaf(S##wx, gx, e.x), qv);                                                                       \
         const float sf = keep * fmaf(S##t, sfs, sfb);             /* (jb + jj) * step / |r0|, one rounding; 0 where masked */      \
-        a0x = fmaf(keep, gx, a0x); a0y = fmaf(keep, gy, a0y); a0z = fmaf(keep, gz, a0z);                                           \
-        a1x = fmaf(sf, gx, a1x); a1y = fmaf(sf, gy, a1y); a1z = fmaf(sf, gz, a1z);                                                 \
+        q0x = fmaf(keep, gx, q0x); q0y = fmaf(keep, gy, q0y); q0z = fmaf(keep, gz, q0z);                                           \
+        q1x = fmaf(sf, gx, q1x); q1y = fmaf(sf, gy, q1y); q1z = fmaf(sf, gz, q1z);                                                 \
     }
-        for (int jj = LO; jj < HI; jj += 2) {                                      // wave-uniform trip count; two samples in flight
-            GS_DECL(a_);
-            GS_DECL(b_);
-            GS_ISSUE(a_, jj)
-            GS_ISSUE(b_, jj + 1)                                                   // past the end: clamped address, act = false
-            GS_CONSUME(a_)
-            GS_CONSUME(b_)
+        for (int jq = LO; jq < HI; jq += TOMO_JS) {                                // two-level sums (GRAD ACCURACY)
+            float qv = 0.f, q0x = 0.f, q0y = 0.f, q0z = 0.f, q1x = 0.f, q1y = 0.f, q1z = 0.f;
+            const int qe = min(jq + TOMO_JS, HI);
+            for (int jj = jq; jj < qe; jj += 2) {                                  // wave-uniform trip count; two samples in flight
+                GS_DECL(a_);
+                GS_DECL(b_);
+                GS_ISSUE(a_, jj)
+                GS_ISSUE(b_, jj + 1)                                               // past the end: clamped address, act = false
+                GS_CONSUME(a_)
+                GS_CONSUME(b_)
+            }
+            av += qv; a0x += q0x; a0y += q0y; a0z += q0z; a1x += q1x; a1y += q1y; a1z += q1z;
         }
 #undef GS_DECL
 #undef GS_ISSUE

@@ -69,6 +69,7 @@ struct tomo_ctx {
     int fwd_variant = 3;      // 1 ray-driven plain, 2 ray-driven SGPR-base, 3 LDS tile (default)
     int adj_variant = 2;      // 1 global float atomics, 2 LDS tile fixed-point (default)
     int grad_variant = 4;     // 1 plain, 2 eight dword gathers + packed lerps, 3 four gathers + DPP neighbour shift, 4 (default) 2 or 3 per pose by tilt
+    int grad_v1_prec = 0;     // diagnostic for grad_variant 1 (per-ray tomo_proj_grad only): bit 0 float64 sample positions, bit 1 float64 lerps and sums
     int tile_flat = 1;      // 1: untilted projections take the flat tile kernels
     int adj_flat_gather = 1;  // 1: untilted unit lattices take the gather-form adjoint (k_adj_gather_flat) instead of the LDS-atomic flat kernel
     int fwd_flat_tab = 1;     // 1 (default): the flat forward with the sample table in LDS and the two images interleaved per plane (k_fwd_flat_tab); 0: the round-2 kernel (k_fwd_flat_z<2>: entries broadcast with v_readlane)

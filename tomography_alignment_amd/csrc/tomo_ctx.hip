@@ -143,6 +143,7 @@ extern "C" int tomo_set_option(tomo_ctx *ctx, const char *key, int value)
     else if (!strcmp(key, "adj_variant")) ctx->adj_variant = value;
     else if (!strcmp(key, "tile_flat")) ctx->tile_flat = value;
     else if (!strcmp(key, "grad_variant")) ctx->grad_variant = value;
+    else if (!strcmp(key, "grad_v1_prec")) ctx->grad_v1_prec = value & 3;
     else if (!strcmp(key, "adj_flat_gather")) ctx->adj_flat_gather = value;
     else if (!strcmp(key, "fwd_flat_ztiles")) ctx->fwd_flat_ztiles = value;
     else if (!strcmp(key, "fwd_flat_wide")) ctx->fwd_flat_wide = value;

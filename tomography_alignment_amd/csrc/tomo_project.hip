@@ -546,8 +546,17 @@ extern "C" int tomo_proj_grad(tomo_ctx *ctx, const double *h_pose, const float *
     rc = upload_projc(ctx, h_pose, 1, true, &d_pc, &d_gc, nullptr, &n_plain);
     if (rc) return rc;
     const int variant = ctx->wide_rows ? 1 : ctx->grad_variant == 4 ? (n_plain ? 2 : 3) : ctx->grad_variant;       // 4 = by tilt
-    if (variant == 1)
+    if (variant == 1 && ctx->grad_v1_prec == 0)
         TOMO_LAUNCH(ctx, "k_proj_grad", k_proj_grad<false>, ray_grid(g, 1), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, d_proj, d_grad,
+                    (const float *)nullptr, (float *)nullptr, (double *)nullptr, g, row_order);
+    else if (variant == 1 && ctx->grad_v1_prec == 1)      // diagnostics: float64 sample positions / float64 lerps and sums / both
+        TOMO_LAUNCH(ctx, "k_proj_grad", (k_proj_grad<false, 1>), ray_grid(g, 1), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, d_proj, d_grad,
+                    (const float *)nullptr, (float *)nullptr, (double *)nullptr, g, row_order);
+    else if (variant == 1 && ctx->grad_v1_prec == 2)
+        TOMO_LAUNCH(ctx, "k_proj_grad", (k_proj_grad<false, 2>), ray_grid(g, 1), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, d_proj, d_grad,
+                    (const float *)nullptr, (float *)nullptr, (double *)nullptr, g, row_order);
+    else if (variant == 1)
+        TOMO_LAUNCH(ctx, "k_proj_grad", (k_proj_grad<false, 3>), ray_grid(g, 1), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, d_proj, d_grad,
                     (const float *)nullptr, (float *)nullptr, (double *)nullptr, g, row_order);
     else if (variant == 2)
         TOMO_LAUNCH(ctx, "k_proj_grad", k_proj_grad_v2<false>, ray_grid(g, 1), dim3(256), 0, d_pc, d_gc, ctx->d_volpad, d_proj, d_grad,

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Development aid: for one seed of tests/test_gpu_fuzz.py::test_gradient_kernels_agree_on_random_geometry print, per case, pose and kernel,
-the worst well-conditioned ray's error against the float64 oracle and that ray's distance to the nearest cell face."""
+the worst well-conditioned ray's error against the float64 oracle and that ray's distance to the nearest cell face; variant 1 also
+with its diagnostic precisions (option grad_v1_prec).  The CPU model of the same arithmetic: tools/grad_error_model.py."""
 import os
 import sys
 
@@ -44,8 +45,9 @@ for k in range(6):
     P = ProjectionMatrix(geo)
     be = P.backend
     d_x = be.upload(x)
-    for v in (1, 2, 3):
+    for v, prec in ((1, 0), (1, 1), (1, 2), (1, 3), (2, 0), (3, 0)):     # variant 1 also with float64 positions (1), float64 lerps + sums (2), both (3)
         be.ctx.set_option("grad_variant", v)
+        be.ctx.set_option("grad_v1_prec", prec)
         for i in range(n):
             pr, gd = be.empty(n_det), be.empty(6 * n_det)
             be.proj_grad(poses[i:i + 1], d_x, pr, gd)
@@ -54,5 +56,5 @@ for k in range(6):
             err = np.max(np.abs(g - want_g[i]) / np.array(gmax)[:, None], axis=0)
             well = dist[i] >= 2e-5
             j = int(np.argmax(np.where(well, err, 0)))
-            print("case %d shape %s ndet %s tilt %.1f pose %d kernel %d: worst well-conditioned ray %d err %.2e, its face distance %.2e; rays within 1e-4 of a face: %d of %d"
-                  % (k, shape, ndet, np.rad2deg(tilt), i, v, j, err[j], dist[i][j], int(np.sum(dist[i] < 1e-4)), n_det), flush=True)
+            print("case %d shape %s ndet %s tilt %.1f pose %d kernel %d prec %d: worst well-conditioned ray %d err %.2e (row-group maxima %.3g / %.3g), its face distance %.2e; rays within 1e-4 of a face: %d of %d"
+                  % (k, shape, ndet, np.rad2deg(tilt), i, v, prec, j, err[j], gmax[0], gmax[3], dist[i][j], int(np.sum(dist[i] < 1e-4)), n_det), flush=True)
