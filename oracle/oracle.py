@@ -463,43 +463,59 @@ def sirt(fwd, adj, n_vox, projections, niter, positivity=False, ground_truth=Non
     return rec, rms[:k]
 
 
+class Cgls(object):
+    """recon/cgls.py:7-104, the sparse-matrix branch (`self.method` is undefined in the reference so only the csr path can be meant,
+    :51-54), as a stateful object like the reference's class: `fwd` / `adj` may be replaced between two `run` calls while `_r`, `_p`,
+    `_gamma` stay (what golden G11 c / d do to the reference to make its re-initialisation rule fire, :60-68).
+    Pinned by tests/test_oracle_golden.py::test_g11_cgls_restatement_vs_reference_class."""
+
+    def __init__(self, fwd, adj, n_vox, projections, ground_truth=None, rec=None):
+        self.fwd, self.adj = fwd, adj
+        self.b = np.asarray(projections, np.float32).ravel()
+        self.rec = np.zeros(n_vox, np.float32) if rec is None else np.array(rec, np.float32).ravel()
+        self.ground_truth = ground_truth
+        self.reinit_lines, self.quit = 0, False
+        self._init()
+
+    def _init(self):                                                    # _initialize, :26-36
+        self._r = self.b - np.asarray(self.fwd(self.rec), np.float32).ravel()
+        self._p = np.asarray(self.adj(self._r), np.float32).ravel()
+        self._gamma = np.linalg.norm(self._p) ** 2
+
+    def run(self, niter):                                               # run_main_iteration, :38-104
+        b, rec = self.b, self.rec
+        norm_factor = np.linalg.norm(b) if self.ground_truth is None else np.linalg.norm(self.ground_truth)
+        rms = np.zeros(niter)
+        conv = np.zeros(niter)
+        k, reinit_iter = 0, 0
+        while k < niter:
+            r = np.asarray(self.fwd(self._p), np.float32).ravel()       # :54
+            a = self._gamma / np.linalg.norm(r) ** 2                    # :56
+            rec += (a * self._p).astype(np.float32)                     # :57
+            conv[k] = np.linalg.norm(b - np.asarray(self.fwd(rec), np.float32).ravel())     # :58-59
+            if k > 0 and conv[k] > conv[k - 1]:                         # :60
+                self.reinit_lines += 1
+                if reinit_iter + 1 == k:                                # :63 (reinit_iter starts at 0: a rise at k = 1 quits)
+                    self.quit = True
+                    return rec, rms[:k]
+                rec -= (a * self._p).astype(np.float32)                 # :66
+                self._init()                                            # :67
+                reinit_iter = k
+            self._r = self._r - (a * r).astype(np.float32)              # :70 (after a re-initialisation: the step and r of before it)
+            p = np.asarray(self.adj(self._r), np.float32).ravel()       # :72
+            gamma = np.linalg.norm(p) ** 2
+            beta = gamma / self._gamma
+            self._gamma = gamma
+            self._p = (p + beta * self._p).astype(np.float32)           # :78
+            rms[k] = (np.linalg.norm(self._r) / norm_factor if self.ground_truth is None
+                      else np.linalg.norm(rec - np.asarray(self.ground_truth).ravel()) / norm_factor)   # :79-82
+            k += 1
+        return rec, rms[:k]
+
+
 def cgls(fwd, adj, n_vox, projections, niter, ground_truth=None, rec=None):
-    """recon/cgls.py:26-104 (the sparse-matrix branch; `self.method` is undefined in the
-    reference so only the csr path can be meant, recon/cgls.py:51-54)."""
-    b = np.asarray(projections, np.float32).ravel()
-    rec = np.zeros(n_vox, np.float32) if rec is None else np.array(rec, np.float32).ravel()
-
-    def init():
-        r_ = b - np.asarray(fwd(rec), np.float32).ravel()
-        p_ = np.asarray(adj(r_), np.float32).ravel()
-        return r_, p_, np.linalg.norm(p_) ** 2
-
-    _r, _p_, _gamma = init()
-    norm_factor = np.linalg.norm(b) if ground_truth is None else np.linalg.norm(ground_truth)
-    rms = np.zeros(niter)
-    conv = np.zeros(niter)
-    k, reinit_iter = 0, 0
-    while k < niter:
-        r = np.asarray(fwd(_p_), np.float32).ravel()
-        a = _gamma / np.linalg.norm(r) ** 2
-        rec += (a * _p_).astype(np.float32)
-        conv[k] = np.linalg.norm(b - np.asarray(fwd(rec), np.float32).ravel())
-        if k > 0 and conv[k] > conv[k - 1]:
-            if reinit_iter + 1 == k:
-                return rec, rms[:k]
-            rec -= (a * _p_).astype(np.float32)
-            _r, _p_, _gamma = init()
-            reinit_iter = k
-        _r = _r - (a * r).astype(np.float32)
-        p = np.asarray(adj(_r), np.float32).ravel()
-        gamma = np.linalg.norm(p) ** 2
-        beta = gamma / _gamma
-        _gamma = gamma
-        _p_ = (p + beta * _p_).astype(np.float32)
-        rms[k] = (np.linalg.norm(_r) / norm_factor if ground_truth is None
-                  else np.linalg.norm(rec - np.asarray(ground_truth).ravel()) / norm_factor)
-        k += 1
-    return rec, rms[:k]
+    """One run of `Cgls` from a fresh state (recon/cgls.py:26-104)."""
+    return Cgls(fwd, adj, n_vox, projections, ground_truth=ground_truth, rec=rec).run(niter)
 
 
 # ----------------------------------------------------------------------------------------

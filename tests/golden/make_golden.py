@@ -382,7 +382,71 @@ def g10():
          phi=phi, alpha=alpha, beta=beta, xyz=xyz, proj64=np.array(p64), grad64=np.array(g64), proj32=np.array(p32), grad32_fortran_rows=np.array(g32))
 
 
+# ------------------------------------------------------------------ G11 CGLS: the reference's own class on the reference's own CSR
+def g11():
+    """recon/cgls.py::CGLS (the csr branch, :54-82, with the re-initialisation rule :60-68) EXECUTED from the reference tree on the
+    CSR the reference's projection_matrix returns.  The file does not import in its own snapshot for two reasons that are defects of
+    the snapshot, not of this container: it imports `utilities.linear_operators` (:3), a module the repository does not contain and the
+    csr branch never uses, and `run_main_iteration` reads `self.method` (:51), which nothing sets.  Neither is edited: an EMPTY module
+    object stands where the missing one is looked up, and `method` is set on the instance to anything but 'linop' (the only other
+    branch, :52-54, is the csr one).  'precision' is not passed (:20 would index the builtin `object`).
+    Cases: a / b -- G5's sinogram (32^3, 16 angles, jittered poses), 10 iterations, without and with a ground truth;
+    c / d -- 16^3, 6 angles: the re-initialisation rule, once continuing and once quitting (see below)."""
+    sys.modules.setdefault("utilities.linear_operators", types.ModuleType("utilities.linear_operators"))
+    from recon import cgls
+    out = {}
+    g5 = np.load(os.path.join(HERE, "g5_sirt.npz"))
+    N, n_proj = 32, 16
+    geo = geom(n_proj, N)
+    angles = np.array([g5["phi"], g5["alpha"], g5["beta"]]).T
+    x = generate_phantom.shepp3d(N)
+    for tag, gt in (("a", None), ("b", x)):
+        opts = {} if gt is None else {"ground_truth": gt.copy()}
+        c = cgls.CGLS(geo, g5["b"].copy(), angles, g5["xyz"], options=opts)
+        c.method = "csr"
+        rec, err = c.run_main_iteration(niter=10)
+        out["rec_" + tag] = np.array(rec, np.float32)
+        out["err_" + tag] = np.array(err)
+    # c, d: the re-initialisation rule (:60-68).  In float32 on consistent or noisy data ||b - A rec|| never rose in up to 300 iterations
+    # (tried while writing this), so the rule is exercised by what the alignment loop can do to a solver: the poses change under it.
+    # After `first` iterations the instance's operator is replaced by the CSR of shifted poses while `_r`, `_p`, `_gamma` stay -- the
+    # recurrences are then inconsistent with the operator and the true residual rises some iterations later.
+    # c: shifts +-1 px after 3 iterations -> "reinitializing at iteration 6", the run goes on (note `_r -= alpha * r` with the alpha
+    #    and r of BEFORE the re-initialisation, :70);  d: shifts +-2 px after 5 iterations -> the rise comes at k = 1 and, `reinit_iter`
+    #    starting at 0, that counts as "two consecutive iterations": the reference quits and returns rms_error[:1] (:63-65).
+    import io, contextlib
+    N, n_proj = 16, 6
+    geo = geom(n_proj, N)
+    phi = np.linspace(0., np.pi, n_proj)
+    xs = generate_phantom.shepp3d(N)
+    for tag, dpx, first in (("c", 1.0, 3), ("d", 2.0, 5)):
+        rng = np.random.default_rng(111)
+        alpha, beta, xyz = jitter(rng, n_proj, 1.0, 1.5)
+        P = projection_operators.ProjectionMatrix(geo)
+        A = P.projection_matrix(alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz)
+        b = sparse.csr_matrix.dot(A, xs.ravel()).reshape(n_proj, -1).astype(np.float32)
+        angles = np.array([phi, alpha, beta]).T
+        c = cgls.CGLS(geo, b.copy(), angles, xyz, options={})
+        c.method = "csr"
+        rec1, err1 = c.run_main_iteration(niter=first)
+        xyz2 = xyz.copy()
+        xyz2[:, 0] += rng.uniform(-dpx, dpx, n_proj)
+        xyz2[:, 2] += rng.uniform(-dpx, dpx, n_proj)
+        c.xyz_shift = xyz2
+        c.proj_mat = P.projection_matrix(alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz2)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            rec, err = c.run_main_iteration(niter=12)
+        said = buf.getvalue()
+        print("   g11 case %s: %d iterations returned; the reference printed: %r" % (tag, len(err), said))
+        out.update({tag + "_phi": phi, tag + "_alpha": alpha, tag + "_beta": beta, tag + "_xyz": xyz, tag + "_xyz2": xyz2, tag + "_b": b,
+                    tag + "_first": np.array(first), "err1_" + tag: np.array(err1), "rec_" + tag: np.array(rec, np.float32),
+                    "err_" + tag: np.array(err), tag + "_reinit_lines": np.array(said.count("reinitializing")),
+                    tag + "_quit": np.array(int("quitting" in said))})
+    save("g11_cgls", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g7", "g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g7", "g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()

@@ -49,10 +49,8 @@ def test_sharded_sirt_world_of_one_matches_plain(shepp32):
 
 
 def test_cgls_vs_restated_reference(shepp32):
-    """RESTATEMENT-ONLY parity: the reference's recon/cgls.py cannot be imported (it needs a `utilities.linear_operators` module
-    the reference does not contain, :3; `self.method` is undefined, :51), so there is no golden vector -- the device-resident
-    CGLS is compared with the oracle's reading of that source (oracle/oracle.py::cgls), nothing more.  8 iterations are held to
-    1e-5 (measured 2e-7, printed)."""
+    """The device-resident CGLS against the oracle's restatement (oracle/oracle.py::Cgls, itself pinned to the reference's class by
+    golden G11 since round 4; the direct comparison with G11 is the next test).  8 iterations are held to 1e-5 (measured 2e-7, printed)."""
     from oracle import oracle as orc
     from tomography_alignment_amd.recon import cgls
     g = golden("g5_sirt")
@@ -65,6 +63,41 @@ def test_cgls_vs_restated_reference(shepp32):
     rec, err = cgls.CGLS(geo, g["b"].copy(), angles, g["xyz"]).run_main_iteration(niter=8)
     print("CGLS x8 vs the oracle's restatement: rec rel-max %.2e, rms rel %.2e" % (rel_max(rec, want), float(np.max(np.abs(err - want_err) / want_err))))
     assert rel_max(rec, want) < 1e-5 and np.allclose(err, want_err, rtol=1e-5)
+
+
+def test_cgls_vs_reference_golden_g11(shepp32, capsys):
+    """Device-resident CGLS against the REFERENCE'S OWN CLASS (golden G11, round 4: recon/cgls.py::CGLS executed from the reference tree
+    on the CSR its projection_matrix returns; tests/golden/make_golden.py::g11): a / b -- 10 iterations on G5's sinogram without /
+    with a ground truth at 1e-5; c -- the operator swapped under the solver after 3 iterations: the re-initialisation rule fires at
+    iteration 6 and the run continues (recon/cgls.py:60-70); d -- the rise comes at k = 1: the reference quits with one rms value."""
+    from tomography_alignment_amd.recon import cgls
+    g5, g = golden("g5_sirt"), golden("g11_cgls")
+    geo = geom(16, 32)
+    angles = np.array([g5["phi"], g5["alpha"], g5["beta"]]).T
+    for tag, gt in (("a", None), ("b", shepp32)):
+        opts = {} if gt is None else {"ground_truth": gt.copy()}
+        rec, err = cgls.CGLS(geo, g5["b"].copy(), angles, g5["xyz"], options=opts).run_main_iteration(niter=10)
+        e, er = rel_max(rec, g["rec_" + tag]), float(np.max(np.abs(err - g["err_" + tag]) / g["err_" + tag]))
+        with capsys.disabled():
+            print("CGLS x10 vs the reference's class (G11 %s): rec rel-max %.2e, rms rel %.2e" % (tag, e, er))
+        assert e < 1e-5 and er < 1e-5
+    for tag in ("c", "d"):
+        geo = geom(6, 16)
+        ang = np.array([g[tag + "_phi"], g[tag + "_alpha"], g[tag + "_beta"]]).T
+        capsys.readouterr()
+        c = cgls.CGLS(geo, g[tag + "_b"].copy(), ang, g[tag + "_xyz"])
+        rec, err1 = c.run_main_iteration(niter=int(g[tag + "_first"]))
+        c.xyz_shift = g[tag + "_xyz2"]
+        c.proj_mat = c.f_proj_obj.projection_matrix(phi=ang[:, 0], alpha=ang[:, 1], beta=ang[:, 2], xyz_shift=g[tag + "_xyz2"])
+        rec, err = c.run_main_iteration(niter=12)
+        said = capsys.readouterr().out
+        assert np.allclose(err1, g["err1_" + tag], rtol=1e-5)
+        assert len(err) == len(g["err_" + tag]) and said.count("reinitializing") == int(g[tag + "_reinit_lines"]) and int("quitting" in said) == int(g[tag + "_quit"])
+        e = rel_max(rec, g["rec_" + tag])
+        er = float(np.max(np.abs(err - g["err_" + tag]) / g["err_" + tag]))
+        with capsys.disabled():
+            print("CGLS re-initialisation (G11 %s): %d iterations, rec rel-max %.2e, rms rel %.2e" % (tag, len(err), e, er))
+        assert e < 2e-5 and er < 2e-5          # the swap makes the iteration ill-conditioned on purpose: an operator rounding is amplified (measured, printed)
 
 
 def test_linear_operators_module(shepp32):

@@ -178,6 +178,40 @@ def test_cgls_control_flow_vs_restated_reference(shepp32):
     assert err[-1] < err[0]
 
 
+def _g11_swap_case(g, tag, backend_of):
+    """The package's CGLS class through golden G11's operator swap (what make_golden.py::g11 does to the reference's class)."""
+    geo = geom(6, 16)
+    angles = np.array([g[tag + "_phi"], g[tag + "_alpha"], g[tag + "_beta"]]).T
+    c = cgls.CGLS(geo, g[tag + "_b"].copy(), angles, g[tag + "_xyz"], options=backend_of(geo))
+    rec, err1 = c.run_main_iteration(niter=int(g[tag + "_first"]))
+    c.xyz_shift = g[tag + "_xyz2"]
+    c.proj_mat = c.f_proj_obj.projection_matrix(phi=angles[:, 0], alpha=angles[:, 1], beta=angles[:, 2], xyz_shift=g[tag + "_xyz2"])
+    rec, err = c.run_main_iteration(niter=12)
+    return err1, rec, err
+
+
+def test_cgls_class_vs_reference_golden_g11(shepp32, capsys):
+    """The package's recon/cgls.py::CGLS (CPU stand-in backend) against the reference's own class run on its own CSR (golden G11):
+    plain runs, the re-initialisation that continues (c) and the one that quits at k = 1 (d) -- control flow, printed lines, and
+    the `_r -= alpha * r` after a re-initialisation (recon/cgls.py:60-70)."""
+    g5, g = golden("g5_sirt"), golden("g11_cgls")
+    geo = geom(16, 32)
+    angles = np.array([g5["phi"], g5["alpha"], g5["beta"]]).T
+    for tag, gt in (("a", None), ("b", shepp32)):
+        opts = {"_backend": OracleBackend(geo)}
+        if gt is not None:
+            opts["ground_truth"] = gt.copy()
+        rec, err = cgls.CGLS(geo, g5["b"].copy(), angles, g5["xyz"], options=opts).run_main_iteration(niter=10)
+        assert rel_max(rec, g["rec_" + tag]) < 2e-5 and np.allclose(err, g["err_" + tag], rtol=2e-5)
+    for tag in ("c", "d"):
+        capsys.readouterr()
+        err1, rec, err = _g11_swap_case(g, tag, lambda geo_: {"_backend": OracleBackend(geo_)})
+        said = capsys.readouterr().out
+        assert np.allclose(err1, g["err1_" + tag], rtol=2e-5)
+        assert len(err) == len(g["err_" + tag]) and said.count("reinitializing") == int(g[tag + "_reinit_lines"]) and int("quitting" in said) == int(g[tag + "_quit"])
+        assert rel_max(rec, g["rec_" + tag]) < 5e-5 and np.allclose(err, g["err_" + tag], rtol=5e-5)
+
+
 def _alignment_setup(shepp32):
     g = golden("g6_alignment")
     geo = geom(1, 32)

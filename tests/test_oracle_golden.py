@@ -125,6 +125,40 @@ def test_g5_sirt(shepp32):
     assert np.allclose(err, g["err_pos_gt"], rtol=2e-5)
 
 
+def _g11_ops(G, g, tag, which):
+    kw = dict(alpha=g[tag + "_alpha"], beta=g[tag + "_beta"], phi=g[tag + "_phi"], xyz_shift=g[tag + "_" + which])
+    return (lambda x: orc.forward(G, x, **kw).astype(np.float32).ravel()), (lambda y: orc.adjoint(G, y, **kw).astype(np.float32))
+
+
+def test_g11_cgls_restatement_vs_reference_class(shepp32):
+    """G11 (round 4): oracle.Cgls against the reference's own recon/cgls.py::CGLS executed on the reference's own CSR
+    (tests/golden/make_golden.py::g11) -- a / b: 10 iterations on G5's sinogram without / with a ground truth; c: the operator is
+    swapped under the solver after 3 iterations, the re-initialisation rule fires at iteration 6 and the run continues; d: after 5
+    iterations with a larger swap, the rise comes at k = 1 and the reference quits with one rms value."""
+    g5, g = golden("g5_sirt"), golden("g11_cgls")
+    G = geo(16, 32)
+    kw = dict(alpha=g5["alpha"], beta=g5["beta"], phi=g5["phi"], xyz_shift=g5["xyz"])
+    fwd = lambda x: orc.forward(G, x, **kw).astype(np.float32).ravel()   # noqa: E731
+    adj = lambda y: orc.adjoint(G, y, **kw).astype(np.float32)           # noqa: E731
+    for tag, gt in (("a", None), ("b", shepp32)):
+        rec, err = orc.cgls(fwd, adj, G.n_vox, g5["b"], 10, ground_truth=gt)
+        e = rel_max(rec, g["rec_" + tag])
+        print("G11 %s: rec rel-max %.2e, rms rel %.2e" % (tag, e, float(np.max(np.abs(err - g["err_" + tag]) / g["err_" + tag]))))
+        assert e < 2e-5 and np.allclose(err, g["err_" + tag], rtol=2e-5)
+    G = geo(6, 16)
+    for tag in ("c", "d"):
+        f1, a1 = _g11_ops(G, g, tag, "xyz")
+        c = orc.Cgls(f1, a1, G.n_vox, g[tag + "_b"])
+        rec, err = c.run(int(g[tag + "_first"]))
+        assert np.allclose(err, g["err1_" + tag], rtol=2e-5)
+        c.fwd, c.adj = _g11_ops(G, g, tag, "xyz2")
+        rec, err = c.run(12)
+        assert len(err) == len(g["err_" + tag]) and c.reinit_lines == int(g[tag + "_reinit_lines"]) and int(c.quit) == int(g[tag + "_quit"])
+        e = rel_max(rec, g["rec_" + tag])
+        print("G11 %s: %d iterations, re-initialisations %d, quit %d; rec rel-max %.2e" % (tag, len(err), c.reinit_lines, c.quit, e))
+        assert e < 5e-5 and np.allclose(err, g["err_" + tag], rtol=5e-5)
+
+
 def test_g8_voxel_splat():
     g = golden("g8_voxel_splat")
     x = golden("g7_phantom")["shepp16"]
