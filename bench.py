@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="N=1 only: run the multi-GPU code path (sharded solver, x-slab pipelined all-reduce) on a 1-rank RCCL communicator")
     ap.add_argument("--slabs", type=int, default=None, help="x slabs of the sharded solver's pipelined iteration (default: the solver's own)")
+    ap.add_argument("--no-shard-update", action="store_true",
+                    help="sharded solver: all-reduce every slab and update the whole replica on every rank (round 3) instead of reduce-scatter -> "
+                         "update of the rank's own 1/P -> all-gather")
     ap.add_argument("--fwd-variant", type=int, default=None)
     ap.add_argument("--adj-variant", type=int, default=None)
     args = ap.parse_args()
@@ -206,6 +209,8 @@ def main():
 
     if args.slabs is not None:
         sirt_mpi.SIRT.n_pipeline_slabs = int(args.slabs)
+    if args.no_shard_update:
+        sirt_mpi.SIRT.shard_update = False
 
     def make_solver(tilted):
         alpha, beta, xyz = poses_for(tilted)
@@ -241,17 +246,22 @@ def main():
     # ---- per-kernel timing of the timed region (HIP events on the stream each kernel / collective runs on)
     kern = {}
     for name in ("k_fwd_v1", "k_fwd_v2", "k_fwd_tile", "k_fwd_tile_flat", "k_fwd_live", "k_adj_v1", "k_adj_tile", "k_adj_tile_flat", "k_adj_gather_flat", "k_pad", "k_unpad",
-                 "k_absmax", "k_sino_zflags", "k_residual_scale", "k_update", "k_vec", "allreduce_f32", "comm_join_wait"):
+                 "k_absmax", "k_sino_zflags", "k_residual_scale", "k_update", "k_vec", "allreduce_f32", "reduce_scatter_f32", "allgather_f32", "comm_join_wait"):
         n, ms = ctx.profile_get(name)
         if n:
             # a pass over all angles may be issued as several launches (x slabs of the pipelined back-projection):
             # ms_per_step sums them, so work-per-pass / ms_per_step == work-per-launch / avg launch time
             kern[name] = {"launches": n, "avg_ms": ms / n, "launches_per_step": n / float(args.steps), "ms_per_step": ms / float(args.steps)}
-    if "allreduce_f32" in kern:
-        # bytes each rank hands to the collective per step (the voxel update, float32) and what a ring moves per rank for it
-        kern["allreduce_f32"]["bytes_per_step"] = 4.0 * N ** 3
-        kern["allreduce_f32"]["ring_bytes_per_rank_per_step"] = 2.0 * (world - 1) / world * 4.0 * N ** 3
-        kern["allreduce_f32"]["exposed_ms_per_step"] = kern.get("comm_join_wait", {}).get("ms_per_step", kern["allreduce_f32"]["ms_per_step"])
+    # bytes each rank hands to the collectives per step (the voxel update, float32) and what a ring moves per rank for them: an
+    # all-reduce of the volume, or (round 4: the update sharded over the ranks) its two halves -- reduce-scatter, then all-gather
+    for cname, ring in (("allreduce_f32", 2.0), ("reduce_scatter_f32", 1.0), ("allgather_f32", 1.0)):
+        if cname in kern:
+            kern[cname]["bytes_per_step"] = 4.0 * N ** 3
+            kern[cname]["ring_bytes_per_rank_per_step"] = ring * (world - 1) / world * 4.0 * N ** 3
+    comm_names = [c for c in ("allreduce_f32", "reduce_scatter_f32", "allgather_f32") if c in kern]
+    if comm_names:
+        total = sum(kern[c]["ms_per_step"] for c in comm_names)
+        kern[comm_names[0]]["exposed_ms_per_step"] = kern.get("comm_join_wait", {}).get("ms_per_step", total)      # of all collectives of the step together
     n_loc = my_rows.size
     n_det = N * N
     alg_fwd = n_loc * (4.0 * N ** 3 + 4.0 * n_det)               # bytes per forward launch   

@@ -109,7 +109,14 @@ TOMO_API int tomo_sync(tomo_ctx *ctx);
  *   "reuse_sino_flags" 1: the caller vouches that the sinogram passed to tomo_adjoint / tomo_adjoint_xslab has not changed since the
  *                 previous such call with the same pointer and number of projections, so the scan that marks its non-empty detector-z
  *                 planes is not repeated (the x-slab calls of ONE back-projection pass: the solver sets it for slabs 2..n); default 0.
- *                 Any forward call, and any call with another pointer or size, drops the cached marks */
+ *                 A call with another pointer, number of projections, detector shape, volume height or set of integer pose z offsets
+ *                 finds the marks stale and scans again; so does the first back-projection after a forward call that took the tile
+ *                 kernels (their block lists share the buffer) or after tomo_set_geometry
+ *   "grad_v1_prec" 0..3 (diagnostic, tomo_proj_grad with grad_variant 1 only): bit 0 float64 sample positions, bit 1 float64 lerps and
+ *                 sums -- shows which float32 step an error comes from (profiles/round4_grad_error_model.md); default 0
+ *   "comm_test_poison_us" n (tests only): every asynchronous collective first doubles its buffer, idles n microseconds and halves it
+ *                 again on the communication stream, so that a compute-stream kernel that did not wait for it is caught by a
+ *                 one-rank run; default 0 */
 TOMO_API int tomo_set_option(tomo_ctx *ctx, const char *key, int value);
 
 /* Geometry: replaces passing a `Geometry` object to utilities/ray_voxel_utilities.py:53,113.
@@ -239,6 +246,9 @@ TOMO_API int tomo_vec_soft_threshold(tomo_ctx *ctx, float *d_out, const float *d
 TOMO_API int tomo_tv_denoise_fista(tomo_ctx *ctx, const float *d_im, float *d_out, int nx, int ny, int nz, double weight, int niter, double eps,
                           int check_gap_frequency, int *h_iters, double *h_dual_gap);
 TOMO_API int tomo_tv_norm_3d(tomo_ctx *ctx, const float *d_x, int nx, int ny, int nz, double *h_norm);
+/* tomo_tv_denoise_fista keeps its workspace (7 volumes: the dual fields and two images) in the context between calls, grow-only;
+ * tomo_release_workspace frees it (synchronises the stream first).  The next call that needs it allocates it again. */
+TOMO_API int tomo_release_workspace(tomo_ctx *ctx);
 
 /* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI)
  * Replaces mpi4py COMM_WORLD Allreduce(SUM) of recon/sirt_mpi.py:68,103 and recon/cgls_mpi.py:55,98
@@ -252,8 +262,19 @@ TOMO_API int tomo_allreduce_sum_f32(tomo_ctx *ctx, float *d_buf, int64_t n);    
  * stream; tomo_comm_join makes the compute stream wait for every asynchronous all-reduce issued before it. */
 TOMO_API int tomo_allreduce_sum_f32_async(tomo_ctx *ctx, float *d_buf, int64_t n);
 TOMO_API int tomo_comm_join(tomo_ctx *ctx);
-/* the compute stream waits for the OLDEST asynchronous all-reduce not yet waited for (issue order); no-op when none is pending */
+/* the compute stream waits for the OLDEST asynchronous all-reduce / reduce-scatter not yet waited for (issue order); no-op when none is pending */
 TOMO_API int tomo_comm_wait_next(tomo_ctx *ctx);
+/* Sharding the volume-sized vector work of an iteration (round 4): where recon/sirt_mpi.py:101-110 all-reduces the update and every
+ * rank then applies it to its full replica, a rank may instead receive only the sum of ITS 1/P of a segment
+ * (tomo_reduce_scatter_sum_f32_async: in place on d_buf[0 .. n_ranks * n_per_rank), rank r's sums land in d_buf + r * n_per_rank,
+ * the other pieces are left undefined), update that piece of the reconstruction, and hand the pieces round
+ * (tomo_allgather_f32_async: in place, rank r contributes d_buf + r * n_per_rank).  Same bytes on the links as the all-reduce (a ring
+ * all-reduce IS these two phases), 1/P of the update / scaling / error-sum work per rank.  Both run on the communication stream like
+ * tomo_allreduce_sum_f32_async; all-gathers have a wait queue of their own (tomo_comm_wait_next_gather), so a caller can wait for
+ * "reduce-scatter of slab s + 1" before "all-gather of slab s" although they were issued the other way round. */
+TOMO_API int tomo_reduce_scatter_sum_f32_async(tomo_ctx *ctx, float *d_buf, int64_t n_per_rank);
+TOMO_API int tomo_allgather_f32_async(tomo_ctx *ctx, float *d_buf, int64_t n_per_rank);
+TOMO_API int tomo_comm_wait_next_gather(tomo_ctx *ctx);
 TOMO_API int tomo_allreduce_sum_f64_host(tomo_ctx *ctx, double *h_vals, int n);  /* small host scalars */
 TOMO_API int tomo_allreduce_max_f64_host(tomo_ctx *ctx, double *h_vals, int n);
 

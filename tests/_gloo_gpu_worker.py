@@ -43,6 +43,39 @@ class HostStagedComm(object):
     def wait_next(self):
         self.n_wait += 1
 
+    # round 4: reduce-scatter (the pieces this rank does not own are left as NaN, as undefined as RCCL leaves them) and all-gather
+    def reduce_scatter_sum_async(self, buf, n_per_rank):
+        import torch
+        n = int(n_per_rank)
+        if n:
+            seg = buf.view(0, n * self.size)
+            h = seg.download()
+            self.dist.all_reduce(torch.from_numpy(h))
+            mine = h[self.rank * n:(self.rank + 1) * n].copy()
+            if self.size > 1:
+                h[:] = np.nan
+            h[self.rank * n:(self.rank + 1) * n] = mine
+            seg.upload(h)
+        self.n_rs = getattr(self, "n_rs", 0) + 1
+        return buf
+
+    def allgather_async(self, buf, n_per_rank):
+        import torch
+        n = int(n_per_rank)
+        if n:
+            seg = buf.view(0, n * self.size)
+            h = seg.download()
+            parts = [torch.empty(n, dtype=torch.float32) for _ in range(self.size)]
+            self.dist.all_gather(parts, torch.from_numpy(h[self.rank * n:(self.rank + 1) * n].copy()))
+            for q, part in enumerate(parts):
+                h[q * n:(q + 1) * n] = part.numpy()
+            seg.upload(h)
+        self.n_ag = getattr(self, "n_ag", 0) + 1
+        return buf
+
+    def wait_next_gather(self):
+        pass
+
     def join(self):
         pass
 
@@ -92,15 +125,17 @@ def main(out_path):
         full = HipBackend(geo, ctx=ctx)
         b = full.forward(_lib.poses_array(phi, alpha, beta, xyz, cor), full.upload(x), full.empty(n_proj * ndet[0] * ndet[1])).download().reshape(n_proj, -1)
         mine = np.array_split(np.arange(n_proj), comm.size)[comm.rank]
-        for mode in ("pipelined", "plain"):
-            comm.force_pipeline = mode == "pipelined"
+        for mode in ("pipelined", "allreduce", "plain"):     # reduce-scatter / all-gather slabs; all-reduce slabs (round 3); one whole-volume all-reduce
+            comm.force_pipeline = mode != "plain"
             s = sirt_mpi.SIRT(comm, geo, b.copy(), ang, xyz, options={"_backend": HipBackend(sirt_mpi.SIRT._shard_geometry(geo, mine), ctx=ctx), "ground_truth": x})
             if mode == "plain":
                 s.n_pipeline_slabs = 1
-            v0, s0 = comm.n_vol_allreduce, comm.n_slab_allreduce
+            s.shard_update = mode == "pipelined"
+            v0, s0, r0, a0 = comm.n_vol_allreduce, comm.n_slab_allreduce, getattr(comm, "n_rs", 0), getattr(comm, "n_ag", 0)
             rec, err = s.run_main_iteration(niter=5, positivity=True)
             out["%s_%s_rec" % (tag, mode)], out["%s_%s_err" % (tag, mode)] = rec, err
             out["%s_%s_nvol" % (tag, mode)], out["%s_%s_nslab" % (tag, mode)] = comm.n_vol_allreduce - v0, comm.n_slab_allreduce - s0
+            out["%s_%s_nrs" % (tag, mode)], out["%s_%s_nag" % (tag, mode)] = getattr(comm, "n_rs", 0) - r0, getattr(comm, "n_ag", 0) - a0
             out["%s_%s_pipelined" % (tag, mode)] = s._iter_pipelined
     if comm.rank == 0:
         np.savez(out_path, **out)

@@ -31,7 +31,15 @@ def main(out_path):
     assert np.array_equal(s.my_index, my) and s.proj_mat.shape[0] == my.size * N * N
     rec, err = s.run_main_iteration(niter=6, positivity=True)
     n_allreduce_sirt, n_slab_sirt, pipelined = comm.n_vol_allreduce, comm.n_slab_allreduce, s._pipelined
+    n_rs, n_ag, n_wg = getattr(comm, "n_reduce_scatter", 0), getattr(comm, "n_allgather", 0), getattr(comm, "n_wait_gather", 0)
+    slab_sizes = np.array(comm.slab_sizes[:max(1, n_rs + n_slab_sirt) // max(1, len(err))], np.int64)     # the first iteration's collectives
     n_fwd_whole = s.be.calls["forward"]
+    # the round-3 form of the pipelined iteration (all-reduce per slab, the identical update on every rank) must stay equivalent
+    s0_ = comm.n_slab_allreduce
+    sa = sirt_mpi.SIRT(comm, geo, g["b"].copy(), angles, g["xyz"], options={"_backend": OracleBackend(shard)})
+    sa.shard_update = False
+    rec_a, err_a = sa.run_main_iteration(niter=6, positivity=True)
+    n_slab_allreduce_form = comm.n_slab_allreduce - s0_
     # the same run with a stand-in backend that DECLINES the tile kernels on the last rank only (an angle block holding a pose
     # tilted beyond their domain): the decision is collective, so every rank must take the plain sequence -- one whole-volume
     # all-reduce per iteration on every rank, no slab all-reduce anywhere -- and the result must not change
@@ -67,7 +75,8 @@ def main(out_path):
     ares = alignment.align_projections_sharded(comm, OracleBackend(geoa), xa, ba, phia, letters="xzab", bounds=bounds)
     if comm.rank == 0:
         np.savez(out_path, rec=rec, err=err, crec=crec, cerr=cerr, n_allreduce_sirt=n_allreduce_sirt, cor=cor,
-                 n_slab_sirt=n_slab_sirt, pipelined=pipelined, n_fwd_whole=n_fwd_whole, rec_d=rec_d, err_d=err_d,
+                 n_slab_sirt=n_slab_sirt, pipelined=pipelined, n_rs=n_rs, n_ag=n_ag, n_wg=n_wg, slab_sizes=slab_sizes, rec_a=rec_a, err_a=err_a,
+                 n_slab_allreduce_form=n_slab_allreduce_form, n_fwd_whole=n_fwd_whole, rec_d=rec_d, err_d=err_d,
                  declined_pipelined=declined["pipelined"], declined_n_vol=declined["n_vol"], declined_n_slab=declined["n_slab"],
                  rec_g=rec_g, err_g=err_g, rec_p=rec_p, err_p=err_p,
                  align_x=ares["x"], align_fun=ares["fun"], align_true=true, align_nfev=ares["nfev"])

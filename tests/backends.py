@@ -240,6 +240,38 @@ class GlooComm(object):
     def wait_next(self):
         self.n_wait += 1
 
+    # reduce-scatter / all-gather (round 4).  The reduce-scatter POISONS the pieces it does not own (RCCL leaves them undefined): a
+    # solver that read another rank's piece before the all-gather would turn its result into NaN.
+    def reduce_scatter_sum_async(self, buf, n_per_rank):
+        import torch
+        n = int(n_per_rank)
+        seg = buf.a[:n * self.size]
+        t = torch.from_numpy(seg)
+        if t.numel():
+            self.dist.all_reduce(t)
+        mine = seg[self.rank * n:(self.rank + 1) * n].copy()
+        if self.size > 1:
+            seg[:] = np.nan
+        seg[self.rank * n:(self.rank + 1) * n] = mine
+        self.n_reduce_scatter = getattr(self, "n_reduce_scatter", 0) + 1
+        self.slab_sizes.append(n * self.size)
+        return buf
+
+    def allgather_async(self, buf, n_per_rank):
+        import torch
+        n = int(n_per_rank)
+        seg = buf.a[:n * self.size]
+        if n:
+            parts = [torch.empty(n, dtype=torch.float32) for _ in range(self.size)]
+            self.dist.all_gather(parts, torch.from_numpy(seg[self.rank * n:(self.rank + 1) * n].copy()))
+            for q, part in enumerate(parts):
+                seg[q * n:(q + 1) * n] = part.numpy()
+        self.n_allgather = getattr(self, "n_allgather", 0) + 1
+        return buf
+
+    def wait_next_gather(self):
+        self.n_wait_gather = getattr(self, "n_wait_gather", 0) + 1
+
     def join(self):
         pass
 

@@ -44,12 +44,16 @@ def test_sharded_sirt_world_2_on_the_gpu(tmp_path):
     for tag in ("flat", "tilted"):
         ref = one["%s_plain_rec" % tag]
         for w, name in ((one, "world 1"), (two, "world 2")):
-            for mode in ("pipelined", "plain"):
+            for mode in ("pipelined", "allreduce", "plain"):
                 assert rel_max(w["%s_%s_rec" % (tag, mode)], ref) < 1e-5, (tag, name, mode)
                 assert np.allclose(w["%s_%s_err" % (tag, mode)], one["%s_plain_err" % tag], rtol=1e-5), (tag, name, mode)
-            assert bool(w["%s_pipelined_pipelined" % tag]) and not bool(w["%s_plain_pipelined" % tag])
-        # 5 iterations (counted after the constructor's all-reduce of V): pipelined = 6 slab all-reduces per iteration and no
-        # whole-volume one; plain = one whole-volume all-reduce per iteration
-        assert int(two["%s_pipelined_nvol" % tag]) == 0 and int(two["%s_pipelined_nslab" % tag]) == 5 * 6
+            assert bool(w["%s_pipelined_pipelined" % tag]) and bool(w["%s_allreduce_pipelined" % tag]) and not bool(w["%s_plain_pipelined" % tag])
+        # 5 iterations (counted after the constructor's all-reduce of V): pipelined = per iteration 6 slabs, each a reduce-scatter (a rank
+        # receives and updates its own half; the other half is left NaN by the stand-in communicator) and an all-gather, no all-reduce
+        # of a slab (8000-voxel planes split evenly) or of the volume; "allreduce" = round 3's 6 slab all-reduces per iteration;
+        # plain = one whole-volume all-reduce per iteration
+        assert int(two["%s_pipelined_nvol" % tag]) == 0 and int(two["%s_pipelined_nslab" % tag]) == 0
+        assert int(two["%s_pipelined_nrs" % tag]) == 5 * 6 and int(two["%s_pipelined_nag" % tag]) == 5 * 6
+        assert int(two["%s_allreduce_nvol" % tag]) == 0 and int(two["%s_allreduce_nslab" % tag]) == 5 * 6 and int(two["%s_allreduce_nrs" % tag]) == 0
         assert int(two["%s_plain_nvol" % tag]) == 5 and int(two["%s_plain_nslab" % tag]) == 0
         assert one["%s_plain_err" % tag][-1] < one["%s_plain_err" % tag][0]

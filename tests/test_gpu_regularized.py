@@ -64,3 +64,19 @@ def test_tv_denoise_fista_vs_reference_golden(capsys):
     assert o64.dtype == np.float32 and rel_max(o64, g["tv_a"]) < 1e-5
     tv_denoise.close_context()
     assert tv_denoise._ctx is None and rel_max(tv_denoise.denoise_fista(im, **cases["a"]), g["tv_a"]) < 1e-5
+
+
+def test_tv_workspace_can_be_released():
+    """the TV-FISTA workspace (7 volumes, kept in the context between calls) is handed back by tomo_release_workspace
+    (utilities/tv_denoise.py::release_workspace) and re-allocated by the next call that needs it; results unchanged."""
+    from tomography_alignment_amd import _lib
+    from tomography_alignment_amd.utilities import tv_denoise
+    rng = np.random.default_rng(3)
+    im = rng.uniform(0, 1, (24, 20, 28)).astype(np.float32)
+    ctx = _lib.Context()
+    a = tv_denoise.denoise_fista(im, weight=0.2, niter=12, ctx=ctx)
+    tv_denoise.release_workspace(ctx)
+    tv_denoise.release_workspace(ctx)                       # idempotent
+    b = tv_denoise.denoise_fista(im, weight=0.2, niter=12, ctx=ctx)
+    assert np.array_equal(a, b)
+    ctx.close()

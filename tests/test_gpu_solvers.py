@@ -2,6 +2,8 @@
 kernels, the device phantom, event timing, and RCCL bring-up (1 rank) -- all through the C-ABI."""
 import copy
 
+import time
+
 import numpy as np
 import pytest
 from scipy import optimize
@@ -270,6 +272,21 @@ def test_pipelined_allreduce_path_matches_plain(shepp32):
         assert rel_max(res[True][0], res[False][0]) < 2e-6 and np.allclose(res[True][1], res[False][1], rtol=1e-6)
     be = HipBackend(geo, ctx=ctx)
     assert be.xslab_info() == (3, 16)
+    # The test hook that gives a ONE-rank run teeth (csrc/tomo_ctx.hip::comm_async): with comm_test_poison_us > 0 the
+    # communication stream doubles a collective's buffer, idles, and halves it again before the collective runs -- a compute-stream
+    # kernel that touches the buffer without having waited sees doubled values.  Control first: the same read with and without the wait.
+    v = be.upload(np.full(4096, 3.0, np.float32))
+    ctx.set_option("comm_test_poison_us", 30000)
+    comm.allreduce_sum_async(v)
+    time.sleep(0.01)                                  # the doubling kernel has run, the idle kernel is running
+    unwaited = be.dot(v, v)                           # NOT waited for: reads the doubled buffer (be.dot synchronises the compute stream only)
+    comm.allreduce_sum_async(v)
+    comm.wait_next()
+    comm.wait_next()
+    waited = be.dot(v, v)
+    comm.join()
+    assert unwaited == 4096 * 36.0 and waited == 4096 * 9.0, (unwaited, waited)
+    ctx.set_option("comm_test_poison_us", 0)
     # round 3: the NEXT iteration's forward projection is made slab by slab behind the update (tomo_forward_xslab, tomo_comm_wait_next).
     # A ragged volume with 6 tile columns, flat and tilted poses, positivity and a ground truth (the error sum accumulates over the
     # slabs on the device); per iteration every slab's all-reduce is waited for once and iterations 2.. launch no whole forward.
@@ -291,27 +308,37 @@ def test_pipelined_allreduce_path_matches_plain(shepp32):
         b = orc.forward(og, x, alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz).astype(np.float32)
         ang = np.array([phi, alpha, beta]).T
         res = {}
-        for force, slabs in ((False, 8), (True, 8), (True, 4), (True, 2)):
+        # (force the slab pipeline, slabs, shard the update: reduce-scatter -> update of the own piece -> all-gather [round 4] or
+        #  all-reduce + whole update [round 3], poison: every collective preceded by the doubling / idling / halving of its buffer)
+        for force, slabs, shard, poison in ((False, 8, True, 0), (True, 8, True, 0), (True, 8, True, 300), (True, 8, False, 300), (True, 4, True, 300),
+                                            (True, 2, True, 0), (True, 2, False, 0)):
             comm.force_pipeline = force
             s = sirt_mpi.SIRT(comm, geo2, b.copy(), ang, xyz, options={"_backend": HipBackend(geo2, ctx=ctx), "ground_truth": x})
             s.n_pipeline_slabs = slabs
+            s.shard_update = shard
             assert s._pipelined == force
+            ctx.set_option("comm_test_poison_us", poison)
             ctx.profile_reset()
             ctx.profile_enable(True)
-            res[(force, slabs)] = s.run_main_iteration(niter=5, positivity=True)
+            res[(force, slabs, shard, poison)] = s.run_main_iteration(niter=5, positivity=True)
             ctx.profile_enable(False)
+            ctx.set_option("comm_test_poison_us", 0)
             n_wait = ctx.profile_get("comm_join_wait")[0]
+            n_coll = {k: ctx.profile_get(k)[0] for k in ("allreduce_f32", "reduce_scatter_f32", "allgather_f32")}
             n_fwd = sum(ctx.profile_get(k)[0] for k in ("k_fwd_tile_flat", "k_fwd_tile"))
             if force:
                 n_slab = len(s._plan)
                 n_fslab = sum(1 for _, _, (f0, f1) in s._plan if f1 > f0)   # a one-column first slab has no forward columns ready yet
                 assert n_slab == len(np.unique(np.linspace(0, 6, min(slabs, 6) + 1).astype(int))) - 1 and n_fslab >= n_slab - 1
                 assert sorted(c for _, _, (f0, f1) in s._plan for c in range(f0, f1)) == list(range(6))     # every tile column once
-                assert n_wait == 5 * n_slab, (n_wait, n_slab)          # each slab's all-reduce waited for exactly once per iteration
+                # every collective is waited for exactly once per iteration: one all-reduce per slab, or a reduce-scatter and an all-gather
+                assert n_wait == 5 * n_slab * (2 if shard else 1), (n_wait, n_slab)
+                assert n_coll == ({"allreduce_f32": 0, "reduce_scatter_f32": 5 * n_slab, "allgather_f32": 5 * n_slab} if shard else
+                                  {"allreduce_f32": 5 * n_slab, "reduce_scatter_f32": 0, "allgather_f32": 0}), n_coll
                 assert n_fwd == 1 + 4 * n_fslab, (n_fwd, n_fslab)      # iteration 1 whole; 2..5 slab by slab; none made ahead after the last
             else:
                 assert n_wait == 0 and n_fwd == 5
-        ref = res[(False, 8)]
+        ref = res[(False, 8, True, 0)]
         for key, got in res.items():
             assert rel_max(got[0], ref[0]) < 2e-6 and np.allclose(got[1], ref[1], rtol=1e-6), (tilt, key)
         assert ref[1][-1] < ref[1][0]

@@ -83,6 +83,7 @@ SIGNATURES = {
     "tomo_tv_denoise_fista": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
                                              ctypes.c_int, ctypes.POINTER(ctypes.c_int), _c_dp]),
     "tomo_tv_norm_3d": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp]),
+    "tomo_release_workspace": (ctypes.c_int, [_c_vp]),
     "tomo_comm_get_unique_id": (ctypes.c_int, [_c_vp]),
     "tomo_comm_init": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int]),
     "tomo_comm_destroy": (ctypes.c_int, [_c_vp]),
@@ -90,6 +91,9 @@ SIGNATURES = {
     "tomo_allreduce_sum_f32_async": (ctypes.c_int, [_c_vp, _c_vp, _c_i64]),
     "tomo_comm_join": (ctypes.c_int, [_c_vp]),
     "tomo_comm_wait_next": (ctypes.c_int, [_c_vp]),
+    "tomo_reduce_scatter_sum_f32_async": (ctypes.c_int, [_c_vp, _c_vp, _c_i64]),
+    "tomo_allgather_f32_async": (ctypes.c_int, [_c_vp, _c_vp, _c_i64]),
+    "tomo_comm_wait_next_gather": (ctypes.c_int, [_c_vp]),
     "tomo_allreduce_sum_f64_host": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int]),
     "tomo_allreduce_max_f64_host": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int]),
     "tomo_timer_start": (ctypes.c_int, [_c_vp]),

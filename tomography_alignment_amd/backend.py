@@ -100,6 +100,7 @@ class HipBackend(object):
         column range launches nothing)."""
         try:
             self.adjoint_xslab(poses, proj, vol, 0, 0)
+            self.forward_xslab(poses, vol, proj, 0, 0)      # the pipelined update also projects slab by slab: needs fwd_variant 3 as well (ADVICE r3)
             return True
         except _lib.TomoError as e:
             if "do not take the tile kernels" not in str(e):

@@ -213,6 +213,23 @@ class RcclComm(object):
         """The compute stream waits for the oldest allreduce_sum_async it has not waited for yet (issue order)."""
         self.ctx.check(self.ctx.lib.tomo_comm_wait_next(self.ctx.handle))
 
+    def reduce_scatter_sum_async(self, buf, n_per_rank):
+        """Start an in-place reduce-scatter of buf[0 : size * n_per_rank] on the communication stream: afterwards (wait_next) this
+        rank's piece buf[rank * n_per_rank : (rank + 1) * n_per_rank] holds the sum over the ranks; the other pieces are undefined."""
+        assert buf.size >= self.size * n_per_rank
+        self.ctx.check(self.ctx.lib.tomo_reduce_scatter_sum_f32_async(self.ctx.handle, buf.ptr, int(n_per_rank)))
+        return buf
+
+    def allgather_async(self, buf, n_per_rank):
+        """Start an in-place all-gather of buf[0 : size * n_per_rank] (this rank contributes its piece); wait_next_gather()."""
+        assert buf.size >= self.size * n_per_rank
+        self.ctx.check(self.ctx.lib.tomo_allgather_f32_async(self.ctx.handle, buf.ptr, int(n_per_rank)))
+        return buf
+
+    def wait_next_gather(self):
+        """The compute stream waits for the oldest allgather_async it has not waited for yet."""
+        self.ctx.check(self.ctx.lib.tomo_comm_wait_next_gather(self.ctx.handle))
+
     def allreduce_scalar(self, v):
         a = np.array([v], np.float64)
         self.ctx.check(self.ctx.lib.tomo_allreduce_sum_f64_host(self.ctx.handle, _lib.dptr(a), 1))

@@ -172,6 +172,11 @@ __device__ __forceinline__ unsigned tile_cell_dword(unsigned cx, unsigned cy, un
 #define TILE_CLAMP(v, hi) min((v), (unsigned)(hi))
 #define TILE_ZMASK(v) ((v) & 63u)
 #else
+// HARDWARE BEHAVIOUR RELIED ON: out-of-range DS reads return 0 and out-of-range DS writes / atomics are dropped on gfx9 / CDNA.
+// Any other target must build with -DTOMO_TILE_CLAMP (kept in the test matrix: tests/test_gpu_fuzz.py runs against either build).
+#if !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__) && defined(__HIP_DEVICE_COMPILE__)
+#error "k_tile without TOMO_TILE_CLAMP relies on the LDS bounds check of gfx9-family targets"
+#endif
 #define TILE_CLAMP(v, hi) (v)
 #define TILE_ZMASK(v) (v)
 #endif

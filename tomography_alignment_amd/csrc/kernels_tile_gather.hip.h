@@ -150,6 +150,11 @@ __global__ __launch_bounds__(GWAVES * 64, 16 / GWAVES) void k_adj_gather_flat(co
     int nl = 0, rk = 0;
 #pragma unroll
     for (int w = 0; w < GWAVES; ++w) { nl += wlive[w]; rk += w < wv ? wlive[w] : 0; }
+    // HARDWARE BEHAVIOUR RELIED ON (outside the HIP programming model): on gfx9 / CDNA s_barrier counts only the waves of the
+    // work-group that have not terminated, so the live waves may keep calling __syncthreads() after the dead ones returned.
+#if !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__) && defined(__HIP_DEVICE_COMPILE__)
+#error "k_adj_gather_flat: divergent exit before barriers is only known to be safe on gfx9-family targets (s_barrier ignores ended waves)"
+#endif
     if (!zlive) return;
     // a lane is a voxel COLUMN (X, Y) with 64 plane accumulators, except while loading sinogram rows, where it is plane Zl
     const int X = x0 + (lane >> 3), Y = y0 + (lane & 7), Zl = z0 + lane;

@@ -61,6 +61,7 @@ struct tomo_ctx {
     const void *zf_src = nullptr;       // sinogram whose plane flags (+ prefix counts when zf_has_cum) d_blk currently holds; nullptr: none
     int zf_nproj = 0;
     bool zf_has_cum = false, zf_has_shift = false;
+    int zf_ndz = 0, zf_ndx = 0, zf_nz = 0, zf_zc_lo = 0, zf_zc_hi = 0;   // ... and the geometry / pose z offsets they were computed for
     size_t fwd_blk_flat_ints = 0;       // ints of d_blk the flat forward of the current call uses (the general kernel's tile list follows)
     // general float workspace (grow-only): the TV-FISTA proximal step keeps its 7 fields here across calls
     float *d_ws = nullptr;
@@ -86,7 +87,9 @@ struct tomo_ctx {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_compute = nullptr, ev_comm = nullptr;
     bool comm_pending = false;
-    std::deque<hipEvent_t> comm_done;    // one event per asynchronous all-reduce the compute stream has not yet waited for (issue order)
+    std::deque<hipEvent_t> comm_done;    // one event per asynchronous all-reduce / reduce-scatter the compute stream has not yet waited for (issue order)
+    std::deque<hipEvent_t> comm_done_g;  // ... and per asynchronous all-gather
+    int comm_test_poison_us = 0;         // test hook, see comm_async
     std::vector<hipEvent_t> comm_ev_pool;
     int n_ranks = 1, rank = 0;
     std::string err;

@@ -56,6 +56,7 @@ extern "C" int tomo_ctx_destroy(tomo_ctx *c)
     if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     for (auto e : c->comm_done) (void)hipEventDestroy(e);
+    for (auto e : c->comm_done_g) (void)hipEventDestroy(e);
     for (auto e : c->comm_ev_pool) (void)hipEventDestroy(e);
     for (auto &p : c->pending) { c->ev_pool.push_back(p.e0); c->ev_pool.push_back(p.e1); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -144,6 +145,7 @@ extern "C" int tomo_set_option(tomo_ctx *ctx, const char *key, int value)
     else if (!strcmp(key, "tile_flat")) ctx->tile_flat = value;
     else if (!strcmp(key, "grad_variant")) ctx->grad_variant = value;
     else if (!strcmp(key, "grad_v1_prec")) ctx->grad_v1_prec = value & 3;
+    else if (!strcmp(key, "comm_test_poison_us")) ctx->comm_test_poison_us = value;
     else if (!strcmp(key, "adj_flat_gather")) ctx->adj_flat_gather = value;
     else if (!strcmp(key, "fwd_flat_ztiles")) ctx->fwd_flat_ztiles = value;
     else if (!strcmp(key, "fwd_flat_wide")) ctx->fwd_flat_wide = value;
@@ -182,6 +184,19 @@ int tomo_ensure_red(tomo_ctx *ctx, size_t n)
     TOMO_HIP(ctx, hipMalloc((void **)&ctx->d_red, cap * sizeof(double)));
     TOMO_HIP(ctx, hipHostMalloc((void **)&ctx->h_red, cap * sizeof(double), hipHostMallocDefault));
     ctx->red_cap = cap;
+    return TOMO_OK;
+}
+
+// The grow-only workspaces a context keeps between calls can be large (the TV-FISTA proximal step holds 7 volumes: 28 GB at 1024^3):
+// a long-lived context hands them back with this.  The next call that needs one allocates it again.
+extern "C" int tomo_release_workspace(tomo_ctx *ctx)
+{
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    TOMO_HIP(ctx, hipSetDevice(ctx->device));
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    ctx->d_ws = nullptr;
+    ctx->ws_elems = 0;
     return TOMO_OK;
 }
 
@@ -257,6 +272,7 @@ extern "C" int tomo_set_geometry(tomo_ctx *ctx, const tomo_geom *g)
     }
     ctx->halo_dirty = true;
     ctx->staged_src = nullptr;
+    ctx->zf_src = nullptr;                  // cached sinogram plane flags belong to the geometry they were scanned under
     ctx->g = c;
     for (int a = 0; a < 3; ++a) ctx->vox_pitch[a] = g->vox_pitch[a];
     ctx->has_geom = true;
@@ -674,9 +690,27 @@ extern "C" int tomo_allreduce_sum_f32(tomo_ctx *ctx, float *d_buf, int64_t n)
     return TOMO_OK;
 }
 
-extern "C" int tomo_allreduce_sum_f32_async(tomo_ctx *ctx, float *d_buf, int64_t n)
+// Test hook (option comm_test_poison_us, tests only): before an asynchronous collective starts, the communication stream doubles
+// the collective's buffer, idles for that many microseconds and halves it again (exact in float32).  A compute-stream kernel that
+// reads or writes the buffer without having waited for the collective then sees doubled values -- so a ONE-rank run, whose
+// collectives change nothing, can tell a missing wait from a correct one (tests/test_gpu_dist.py).
+__global__ void k_comm_test_scale(float *__restrict__ v, int64_t n, float f)
 {
-    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] *= f;
+}
+__global__ void k_comm_test_idle(long long ticks)      // one wave; wall_clock64 ticks at 100 MHz
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+// The three asynchronous collectives share everything but the RCCL call: they run on the communication stream after everything
+// queued so far on the compute stream, and leave an event in one of two FIFO queues (0: reductions -- all-reduce, reduce-scatter;
+// 1: all-gathers) that tomo_comm_wait_next / tomo_comm_wait_next_gather consume in issue order.
+enum { COLL_ALLREDUCE = 0, COLL_REDUCE_SCATTER = 1, COLL_ALLGATHER = 2 };
+static int comm_async(tomo_ctx *ctx, int kind, float *d_buf, int64_t n)
+{
+    if (!ctx || n < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
     if (!ctx->comm) return ctx->n_ranks == 1 ? TOMO_OK : tomo_fail(ctx, TOMO_ERR_STATE, "comm not initialised");
     if (!ctx->comm_stream) {
         TOMO_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
@@ -685,40 +719,61 @@ extern "C" int tomo_allreduce_sum_f32_async(tomo_ctx *ctx, float *d_buf, int64_t
     }
     TOMO_HIP(ctx, hipEventRecord(ctx->ev_compute, ctx->stream));
     TOMO_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_compute, 0));
-    // profile record "allreduce_f32": on the communication stream, so it holds the collective's own duration (peers' arrival
-    // skew included) whether or not the compute stream ever waits for it -- "comm_join_wait" below is the exposed part
-    tomo_prof_begin_on(ctx, "allreduce_f32", ctx->comm_stream);
-    ncclResult_t r = ncclAllReduce(d_buf, d_buf, (size_t)n, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream);
+    const int64_t n_all = kind == COLL_ALLREDUCE ? n : n * ctx->n_ranks;     // the whole buffer the collective touches
+    float *mine = d_buf + (kind == COLL_ALLREDUCE ? 0 : n * ctx->rank);      // in-place forms: this rank's piece of it
+    if (ctx->comm_test_poison_us > 0 && n_all > 0) {
+        const int grid = (int)std::min<int64_t>((n_all + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_comm_test_scale, dim3(grid), dim3(256), 0, ctx->comm_stream, d_buf, n_all, 2.0f);
+        hipLaunchKernelGGL(k_comm_test_idle, dim3(1), dim3(64), 0, ctx->comm_stream, (long long)ctx->comm_test_poison_us * 100);
+        hipLaunchKernelGGL(k_comm_test_scale, dim3(grid), dim3(256), 0, ctx->comm_stream, d_buf, n_all, 0.5f);
+        TOMO_HIP(ctx, hipGetLastError());
+    }
+    // profile records on the communication stream: they hold the collective's own duration (peers' arrival skew included) whether
+    // or not the compute stream ever waits for it -- "comm_join_wait" is the exposed part
+    static const char *names[3] = {"allreduce_f32", "reduce_scatter_f32", "allgather_f32"};
+    tomo_prof_begin_on(ctx, names[kind], ctx->comm_stream);
+    ncclResult_t r = ncclSuccess;
+    if (n > 0) {
+        if (kind == COLL_ALLREDUCE) r = ncclAllReduce(d_buf, d_buf, (size_t)n, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream);
+        else if (kind == COLL_REDUCE_SCATTER) r = ncclReduceScatter(d_buf, mine, (size_t)n, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream);
+        else r = ncclAllGather(mine, d_buf, (size_t)n, ncclFloat32, ctx->comm, ctx->comm_stream);
+    }
     tomo_prof_end_on(ctx, ctx->comm_stream);
-    if (r != ncclSuccess) return tomo_fail(ctx, TOMO_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    if (r != ncclSuccess) return tomo_fail(ctx, TOMO_ERR_RCCL, std::string(names[kind]) + ": " + ncclGetErrorString(r));
     TOMO_HIP(ctx, hipEventRecord(ctx->ev_comm, ctx->comm_stream));
     ctx->comm_pending = true;
-    // ... and an event of its own, for callers that consume the all-reduces one by one (tomo_comm_wait_next)
+    // ... and an event of its own, for callers that consume the collectives one by one
     hipEvent_t e = nullptr;
     if (!ctx->comm_ev_pool.empty()) { e = ctx->comm_ev_pool.back(); ctx->comm_ev_pool.pop_back(); }
     else TOMO_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     TOMO_HIP(ctx, hipEventRecord(e, ctx->comm_stream));
-    ctx->comm_done.push_back(e);
+    (kind == COLL_ALLGATHER ? ctx->comm_done_g : ctx->comm_done).push_back(e);
     return TOMO_OK;
 }
 
-// The compute stream waits for the OLDEST asynchronous all-reduce it has not waited for yet (issue order).  With this a caller
-// consumes the x slabs of a pipelined update one by one -- slab s is updated, and the next iteration's forward projection of that
-// slab started, while the all-reduces of the later slabs are still on the links (recon/sirt_mpi.py).  No-op when none is pending.
-extern "C" int tomo_comm_wait_next(tomo_ctx *ctx)
+extern "C" int tomo_allreduce_sum_f32_async(tomo_ctx *ctx, float *d_buf, int64_t n) { return comm_async(ctx, COLL_ALLREDUCE, d_buf, n); }
+extern "C" int tomo_reduce_scatter_sum_f32_async(tomo_ctx *ctx, float *d_buf, int64_t n_per_rank) { return comm_async(ctx, COLL_REDUCE_SCATTER, d_buf, n_per_rank); }
+extern "C" int tomo_allgather_f32_async(tomo_ctx *ctx, float *d_buf, int64_t n_per_rank) { return comm_async(ctx, COLL_ALLGATHER, d_buf, n_per_rank); }
+
+// The compute stream waits for the OLDEST asynchronous collective of a queue it has not waited for yet (issue order).  With this a
+// caller consumes the x slabs of a pipelined update one by one -- slab s is updated, and the next iteration's forward projection
+// of that slab started, while the collectives of the later slabs are still on the links (recon/sirt_mpi.py).  No-op when none is pending.
+static int comm_wait_next(tomo_ctx *ctx, std::deque<hipEvent_t> &q)
 {
     if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
-    if (ctx->comm_done.empty()) return TOMO_OK;
-    hipEvent_t e = ctx->comm_done.front();
-    ctx->comm_done.pop_front();
+    if (q.empty()) return TOMO_OK;
+    hipEvent_t e = q.front();
+    q.pop_front();
     tomo_prof_begin(ctx, "comm_join_wait");                  // the same record as tomo_comm_join: exposed communication, summed per step
     hipError_t r = hipStreamWaitEvent(ctx->stream, e, 0);
     tomo_prof_end(ctx);
     ctx->comm_ev_pool.push_back(e);                          // a wait already queued keeps the state the event had when it was queued
     if (r != hipSuccess) return tomo_fail(ctx, TOMO_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(r));
-    if (ctx->comm_done.empty()) ctx->comm_pending = false;
+    if (ctx->comm_done.empty() && ctx->comm_done_g.empty()) ctx->comm_pending = false;
     return TOMO_OK;
 }
+extern "C" int tomo_comm_wait_next(tomo_ctx *ctx) { return ctx ? comm_wait_next(ctx, ctx->comm_done) : tomo_fail(ctx, TOMO_ERR_ARG, "null ctx"); }
+extern "C" int tomo_comm_wait_next_gather(tomo_ctx *ctx) { return ctx ? comm_wait_next(ctx, ctx->comm_done_g) : tomo_fail(ctx, TOMO_ERR_ARG, "null ctx"); }
 
 extern "C" int tomo_comm_join(tomo_ctx *ctx)
 {
@@ -733,6 +788,8 @@ extern "C" int tomo_comm_join(tomo_ctx *ctx)
     }
     for (auto e : ctx->comm_done) ctx->comm_ev_pool.push_back(e);
     ctx->comm_done.clear();
+    for (auto e : ctx->comm_done_g) ctx->comm_ev_pool.push_back(e);
+    ctx->comm_done_g.clear();
     return TOMO_OK;
 }
 

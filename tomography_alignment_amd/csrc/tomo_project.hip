@@ -392,8 +392,11 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
         d_zshift = d_zcum + g.ndz + 1;
         const bool want_cum = n_proj > n_flat;
         // (option "reuse_sino_flags": the x-slab calls of one back-projection pass scan the sinogram once, not once per slab)
+        // The key holds everything the cached words depend on: the sinogram and its shape (layout of d_zf / d_zcum), and the
+        // volume height and the poses' integer z offsets the chunk shift was computed from.
         const bool cached = ctx->reuse_sino_flags && ctx->zf_src == (const void *)d_proj && ctx->zf_nproj == n_proj && (ctx->zf_has_cum || !want_cum) &&
-                            (ctx->zf_has_shift || n_gather == 0);
+                            (ctx->zf_has_shift || n_gather == 0) && ctx->zf_ndz == g.ndz && ctx->zf_ndx == g.ndx && ctx->zf_nz == g.nz &&
+                            ctx->zf_zc_lo == ctx->tile_cache_zc_lo && ctx->zf_zc_hi == ctx->tile_cache_zc_hi;
         if (!cached) {
             TOMO_HIP(ctx, hipMemsetAsync(d_zf, 0, (size_t)g.ndz, ctx->stream));
             const long long n_rows = (long long)n_proj * g.ndx;
@@ -407,6 +410,8 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
             ctx->zf_nproj = n_proj;
             ctx->zf_has_cum = want_cum;
             ctx->zf_has_shift = n_gather > 0;
+            ctx->zf_ndz = g.ndz; ctx->zf_ndx = g.ndx; ctx->zf_nz = g.nz;
+            ctx->zf_zc_lo = ctx->tile_cache_zc_lo; ctx->zf_zc_hi = ctx->tile_cache_zc_hi;
         }
     }
     if (n_gather > 0) {

@@ -6,8 +6,11 @@ recon/sirt_mpi.py:10-146 (`comm` first), with the mpi4py communicator replaced b
 
 Decomposition (recon/sirt_mpi.py:40-49): rank r owns the contiguous angle block
 np.array_split(arange(n_proj), size)[r], its rows of b / W / residual, and a full replica of rec and V.
-Per iteration: ONE all-reduce of the n_vox update V * A_r^T(W_r * res_r) (:101-103) plus one scalar
-all-reduce of ||res_r||^2 (:110); every rank then applies the identical update, so no broadcast.
+Per iteration: ONE sum over the ranks of the n_vox update V * A_r^T(W_r * res_r) (:101-103) plus one scalar
+all-reduce of ||res_r||^2 (:110).  The reference all-reduces and every rank then applies the identical update
+to its replica; the pipelined form here (round 4) reduce-scatters instead: a rank receives the sum of ITS 1/P of
+each slab, updates that piece of `rec` (V scaling, positivity, error sum: 1/P of the volume-sized vector work)
+and the pieces are all-gathered -- the same bytes on the links (a ring all-reduce is these two phases).
 Reference quirks kept: zero guard `< 1e-8` (:69-70) and stop test `k > 1` (:116).
 """
 import copy
@@ -99,13 +102,14 @@ class SIRT(_SIRT):
     def _decide_pipeline(self):
         """Rank-uniform by construction: one scalar all-reduce that EVERY rank issues, whatever it found locally."""
         be, comm = self.be, self.comm
-        wanted = (self.size > 1 or getattr(comm, "force_pipeline", False)) and self.n_pipeline_slabs > 1
         able = all(hasattr(be, a) for a in ("adjoint_xslab", "forward_xslab", "xslab_info", "tiles_take", "update_acc")) and \
             all(hasattr(comm, a) for a in ("allreduce_sum_async", "wait_next", "join")) and self.voxel_mask is None
         if able and self.my_n_proj > 0:
             able = bool(be.tiles_take(self.proj_mat.poses, self.d_res, self.d_bp))
         n_unable = self._allreduce_scalar(0.0 if able else 1.0)
-        self._pipelined = bool(wanted and n_unable == 0)
+        # what every rank CAN do is settled here, collectively; whether the caller WANTS slabs (n_pipeline_slabs, the same on every rank)
+        # is read when an iteration starts (_pipe_now), so it may be set after construction (ADVICE r3)
+        self._pipelined = bool((self.size > 1 or getattr(comm, "force_pipeline", False)) and n_unable == 0)
         self._ax_ready = False
         self._plan_slabs = None
 
@@ -126,8 +130,16 @@ class SIRT(_SIRT):
             return
         super(SIRT, self)._forward()
 
+    shard_update = True       # pipelined form: reduce-scatter -> update of the rank's own 1/P of each slab -> all-gather (False: all-reduce
+                              # + the identical update on every rank, the round-3 form; same on every rank)
+
+    def _pieces(self, n):
+        """A slab of n voxels as size equal pieces + a tail of < size voxels (all-reduced and updated on every rank)."""
+        piece = n // self.size if self.shard_update and all(hasattr(self.comm, a) for a in ("reduce_scatter_sum_async", "allgather_async", "wait_next_gather")) else 0
+        return piece, n - piece * self.size
+
     def _backproject_scaled(self):
-        """recon/sirt_mpi.py:98-103; pipelined form: see above (the all-reduces are consumed by _update)."""
+        """recon/sirt_mpi.py:98-103; pipelined form: see above (the reductions are consumed by _update)."""
         self._iter_pipelined = self._pipe_now()
         if not self._iter_pipelined:
             return super(SIRT, self)._backproject_scaled()
@@ -136,27 +148,66 @@ class SIRT(_SIRT):
         for i, ((xt0, xt1), (x_lo, x_hi), _) in enumerate(self._plan):
             if self.my_n_proj > 0:
                 be.adjoint_xslab(self.proj_mat.poses, self.d_res, self.d_bp, xt0, xt1, same_sinogram=(i > 0))
-            seg = self.d_bp.view(x_lo * plane, (x_hi - x_lo) * plane)
-            comm.allreduce_sum_async(seg)           # issued for EVERY slab on every rank (an empty one too): same sequence everywhere
-                                                    # (the scaling by V -- sirt_mpi.py:101 -- commutes with the sum: applied by the update)
+            o, n = x_lo * plane, (x_hi - x_lo) * plane
+            piece, tail = self._pieces(n)
+            # issued for EVERY slab on every rank (an empty one too): same sequence of collectives everywhere
+            # (the scaling by V -- sirt_mpi.py:101 -- commutes with the sum: applied by the update)
+            if piece:
+                comm.reduce_scatter_sum_async(self.d_bp.view(o, piece * self.size), piece)
+            if tail:
+                comm.allreduce_sum_async(self.d_bp.view(o + piece * self.size, tail))
 
     def _update(self, positivity, last=False):
         if not self._iter_pipelined:
             return super(SIRT, self)._update(positivity, last)
-        be, comm, plane = self.be, self.comm, self._plane
+        be, comm, plane, P, r = self.be, self.comm, self._plane, self.size, self.my_rank
         ahead = not last and self.my_n_proj > 0     # project for the next iteration (wasted only if the stop rule fires now)
         if ahead:
             self.d_ax.zero_()                       # stream order: after the residual kernel has read it
-        for i, (_, (x_lo, x_hi), (f0, f1)) in enumerate(self._plan):
-            comm.wait_next()
-            o, n = x_lo * plane, (x_hi - x_lo) * plane
+        first, gathers, fwd_after = True, 0, None
+
+        def upd(o, n, with_gt):
+            nonlocal first
             be.update_acc(self.d_rec.view(o, n), self.d_bp.view(o, n), self.d_V.view(o, n), positivity,
-                          self.d_gt.view(o, n) if self.d_gt is not None else None, first=(i == 0))
-            if ahead and f1 > f0:
-                be.forward_xslab(self.proj_mat.poses, self.d_rec, self.d_ax, f0, f1)
-        comm.join()                                 # nothing left pending (bookkeeping; every all-reduce has been waited for)
+                          self.d_gt.view(o, n) if (self.d_gt is not None and with_gt) else None, first=first)
+            first = False
+
+        def forward_behind(cols):
+            """The next iteration's forward projection of the tile columns a finished slab completes."""
+            if ahead and cols is not None and cols[1] > cols[0]:
+                be.forward_xslab(self.proj_mat.poses, self.d_rec, self.d_ax, cols[0], cols[1])
+
+        for i, (_, (x_lo, x_hi), cols) in enumerate(self._plan):
+            o, n = x_lo * plane, (x_hi - x_lo) * plane
+            piece, tail = self._pieces(n)
+            if piece:
+                comm.wait_next()                                    # this slab's reduce-scatter: my piece of d_bp is final
+                upd(o + r * piece, piece, True)                     # 1/P of the slab: V scaling, positivity, error sum
+            if tail:
+                comm.wait_next()                                    # the tail's all-reduce
+                upd(o + piece * P, tail, r == 0)                    # identical on every rank; its error counted once
+            if piece:
+                comm.allgather_async(self.d_rec.view(o, piece * P), piece)      # after the update (stream order -> communication stream)
+                gathers += 1
+                # software-pipelined: slab i's pieces travel while slab i + 1 is updated; the forward projection that needs slab i - 1
+                # whole waits for ITS all-gather only
+                if gathers > 1:
+                    comm.wait_next_gather()
+                    forward_behind(fwd_after)
+                fwd_after = cols
+            else:
+                forward_behind(cols)                                # all-reduced slab: final on every rank as soon as it is updated
+        if gathers:
+            comm.wait_next_gather()
+            forward_behind(fwd_after)
+        comm.join()                                 # nothing left pending (bookkeeping; every collective has been waited for)
         self._ax_ready = ahead
-        return be.update_acc_fetch() if self.d_gt is not None else None
+        if self.d_gt is None:
+            return None
+        err = be.update_acc_fetch()
+        # with pieces every rank summed (gt - rec)^2 over its own voxels only (and rank 0 over the tails): one more scalar all-reduce,
+        # issued by every rank alike (whether a ground truth is given is a property of the run, not of a rank)
+        return self._allreduce_scalar(err) if any(self._pieces((x_hi - x_lo) * plane)[0] for _, (x_lo, x_hi), _ in self._plan) else err
 
     def iterate_device(self, niter=100, positivity=False, projections=None, debug=False):
         self._ax_ready = False                      # a projection made ahead never outlives the call that made it

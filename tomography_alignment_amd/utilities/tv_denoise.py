@@ -35,6 +35,14 @@ def close_context():
         c.close()
 
 
+def release_workspace(ctx=None):
+    """Hand the TV workspace (7 volumes, kept in the context between calls) back to the device: call it when the regularised
+    solver is done and the same process goes on to something large (tomo_release_workspace)."""
+    c = ctx if ctx is not None else _ctx
+    if c is not None:
+        c.check(c.lib.tomo_release_workspace(c.handle))
+
+
 def denoise_fista(im, weight=50, niter=200, eps=1.e-5, check_gap_frequency=3, ctx=None, return_info=False):
     """argmin_res 0.5*||im - res||^2 + weight*TV(res) (isotropic TV, FISTA on the dual) -- utilities/tv_denoise.py:98-170.
     Returns the reference's `new`: the iterate of the last dual-gap check -- as FLOAT32 for numpy input of any dtype (the
