@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="N=1 only: run the multi-GPU code path (sharded solver, x-slab pipelined all-reduce) on a 1-rank RCCL communicator")
     ap.add_argument("--slabs", type=int, default=None, help="x slabs of the sharded solver's pipelined iteration (default: the solver's own)")
+    ap.add_argument("--no-cgls", action="store_true", help="skip the CGLS side measurement")
     ap.add_argument("--no-shard-update", action="store_true",
                     help="sharded solver: all-reduce every slab and update the whole replica on every rank (round 3) instead of reduce-scatter -> "
                          "update of the rank's own 1/P -> all-gather")
@@ -159,7 +160,7 @@ def main():
     from tomography_alignment_amd import _lib
     from tomography_alignment_amd.backend import HipBackend
     from tomography_alignment_amd.comm import RcclComm
-    from tomography_alignment_amd.recon import sirt as sirt_mod, sirt_mpi
+    from tomography_alignment_amd.recon import sirt as sirt_mod, sirt_mpi, cgls as cgls_mod
     from tomography_alignment_amd.utilities.geometry import Geometry
     from tomography_alignment_amd.utilities.generate_phantom import SHEPP_LOGAN
 
@@ -266,27 +267,33 @@ def main():
     n_det = N * N
     alg_fwd = n_loc * (4.0 * N ** 3 + 4.0 * n_det)               # bytes per forward launch   
     alg_adj = n_loc * (8.0 * N ** 3 + 4.0 * n_det)               # bytes per back-projection launch
-    fwd_name = next((k for k in ("k_fwd_tile_flat", "k_fwd_tile", "k_fwd_v2", "k_fwd_v1") if k in kern), None)
-    adj_name = next((k for k in ("k_adj_gather_flat", "k_adj_tile_flat", "k_adj_tile", "k_adj_v1") if k in kern), None)
-    cands = []
-    if fwd_name:
-        cands.append((kern[fwd_name]["ms_per_step"], fwd_name, alg_fwd))
-    if adj_name:
-        cands.append((kern[adj_name]["ms_per_step"], adj_name, alg_adj))
-    key = "N%d_A%d_G%d%s%s" % (N, n_proj, world, "_P" if args.perturbed else "", "_D" if args.dense else "")
-    roofline = None
-    if cands:
-        step_ms, name, alg = max(cands)
-        roofline = make_roofline(name, step_ms, kern[name]["launches_per_step"], alg, key, n_loc * float(N) ** 3, 4.0 * n_loc * n_det)
-    extra = {}
-    if fwd_name:
-        extra["forward_alg_GBps"] = round(alg_fwd / (kern[fwd_name]["ms_per_step"] * 1e-3) / 1e9, 1)
-    if adj_name:
-        extra["backproj_alg_GBps"] = round(alg_adj / (kern[adj_name]["ms_per_step"] * 1e-3) / 1e9, 1)
-    # the other projector kernel, priced the same way (secondary)
-    if roofline is not None and len(cands) == 2:
-        o_ms, o_name, o_alg = min(cands)
-        extra["roofline_other_kernel"] = make_roofline(o_name, o_ms, kern[o_name]["launches_per_step"], o_alg, key, n_loc * float(N) ** 3, 4.0 * n_loc * n_det)
+    def roofline_pair(kk, key):
+        """(roofline of the projector kernel that takes most of a step, the other one's, extras) from a {kernel: {ms_per_step, launches_per_step}} table."""
+        fwd = next((k for k in ("k_fwd_tile_flat", "k_fwd_tile", "k_fwd_v2", "k_fwd_v1") if k in kk), None)
+        adj = next((k for k in ("k_adj_gather_flat", "k_adj_tile_flat", "k_adj_tile", "k_adj_v1") if k in kk), None)
+        cands = []
+        if fwd:
+            cands.append((kk[fwd]["ms_per_step"], fwd, alg_fwd))
+        if adj:
+            cands.append((kk[adj]["ms_per_step"], adj, alg_adj))
+        main_r, other_r, ex = None, None, {}
+        if cands:
+            step_ms, name, alg = max(cands)
+            main_r = make_roofline(name, step_ms, kk[name]["launches_per_step"], alg, key, n_loc * float(N) ** 3, 4.0 * n_loc * n_det)
+        if fwd:
+            ex["forward_alg_GBps"] = round(alg_fwd / (kk[fwd]["ms_per_step"] * 1e-3) / 1e9, 1)
+        if adj:
+            ex["backproj_alg_GBps"] = round(alg_adj / (kk[adj]["ms_per_step"] * 1e-3) / 1e9, 1)
+        if main_r is not None and len(cands) == 2:      # the other projector kernel, priced the same way (secondary)
+            o_ms, o_name, o_alg = min(cands)
+            other_r = make_roofline(o_name, o_ms, kk[o_name]["launches_per_step"], o_alg, key, n_loc * float(N) ** 3, 4.0 * n_loc * n_det)
+        return main_r, other_r, ex, fwd, adj
+
+    base_key = "N%d_A%d_G%d" % (N, n_proj, world)
+    key = base_key + ("_P" if args.perturbed else "") + ("_D" if args.dense else "")
+    roofline, other, extra, fwd_name, adj_name = roofline_pair(kern, key)
+    if other is not None:
+        extra["roofline_other_kernel"] = other
 
     its = args.steps / elapsed
     out = {
@@ -330,12 +337,22 @@ def main():
         barrier()
         dt = comm.allreduce_max(time.perf_counter() - t1)
         ctx.profile_enable(False)
-        kk = {}
+        kk, table = {}, {}
         for nm in ("k_fwd_tile", "k_fwd_tile_flat", "k_adj_tile", "k_adj_tile_flat", "k_adj_gather_flat"):
             n, ms = ctx.profile_get(nm)
             if n:
                 kk[nm + "_ms_per_step"] = round(ms / 2.0, 2)
-        return dict({"value": round(2.0 / dt, 6), "unit": "it/s", "steps": 2, "warmup": 1, "config": label}, **kk)
+                table[nm] = {"launches": n, "avg_ms": ms / n, "launches_per_step": n / 2.0, "ms_per_step": ms / 2.0}
+        # the leg's own roofline blocks (VERDICT r3 #2b), from counters committed for ITS workload key (..._P tilted poses, ..._D dense volume;
+        # tools/profile_round.sh takes the PMC passes of `bench.py --perturbed` / `--dense`, the same solver on the same data)
+        leg_key = base_key + ("_P" if tilted else "") + ("_D" if dense else "")
+        main_r, other_r, _, _, _ = roofline_pair(table, leg_key)
+        res = dict({"value": round(2.0 / dt, 6), "unit": "it/s", "steps": 2, "warmup": 1, "config": label}, **kk)
+        if main_r is not None:
+            res["roofline"] = main_r
+        if other_r is not None:
+            res["roofline_other_kernel"] = other_r
+        return res
 
     if not args.no_tilted and not args.perturbed and not args.dense:
         # side measurement (not `value`): alpha, beta ~ U(+-1 deg), tx, tz ~ U(+-2 px), default_rng(0) -- SURVEY 8d's perturbed run:
@@ -345,6 +362,39 @@ def main():
         # side measurement: the same object + 0.05 everywhere, so that no tile is all zero (the headline leans on
         # the zero-tile exits of the tile kernels; Shepp-Logan is exactly zero outside its ellipsoid)
         out["dense_volume"] = side_run(args.perturbed, True, "same workload on a volume with no zero voxel (Shepp-Logan + 0.05): no all-zero tile exits")
+    if not args.no_cgls and not args.perturbed and not args.dense and world == 1:
+        # side measurement: CGLS iterations per second on the same workload -- recon/cgls.py:54-82 has two forward
+        # projections (A p, and A rec for its ||b - A rec|| restart test) and one back-projection per iteration
+        del solver
+        solver = None
+        be.phantom(d_true, (N, N, N), SHEPP_LOGAN)          # the dense leg above added 0.05 in place
+        be.forward(_lib.poses_array(phi[my_rows], 0 * phi[my_rows], 0 * phi[my_rows], np.zeros((my_rows.size, 3)), np.zeros(3)), d_true, d_b)
+        c = cgls_mod.CGLS(geo, d_b, np.array([phi, 0 * phi, 0 * phi]).T, np.zeros((n_proj, 3)), {"_backend": be})
+        c.iterate_device(niter=1)
+        ctx.sync()
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        t1 = time.perf_counter()
+        k_c, rms_c = c.iterate_device(niter=2)
+        ctx.sync()
+        dt = time.perf_counter() - t1
+        ctx.profile_enable(False)
+        kk = {}
+        for nm in ("k_fwd_tile_flat", "k_adj_gather_flat", "k_fwd_live", "k_sino_zflags", "k_vec", "k_dot"):
+            n, ms = ctx.profile_get(nm)
+            if n:
+                kk[nm + "_ms_per_step"] = round(ms / 2.0, 2)
+        out["cgls"] = dict({"value": round(k_c / dt, 6), "unit": "it/s", "steps": int(k_c), "warmup": 1, "rms_error_last": float(rms_c[-1]),
+                            "config": "CGLS (recon/cgls.py:54-82) on the same workload: 2 forward projections + 1 back-projection per iteration"}, **kk)
+        out["cgls_it_per_s"] = out["cgls"]["value"]
+        del c
+    # the rates of the side legs beside `value` (VERDICT r3 #2c): `value` is measured on the Shepp-Logan phantom, a quarter of whose
+    # blocks are all zero and never launched; `value_dense_volume` does all the work; `value_tilted_poses` is what SIRT runs at once an
+    # alignment pass has moved the poses
+    if "dense_volume" in out:
+        out["value_dense_volume"] = out["dense_volume"]["value"]
+    if "tilted_poses" in out:
+        out["value_tilted_poses"] = out["tilted_poses"]["value"]
     if not args.no_align:
         del solver
         out["alignment_gradient"] = align_rate(comm, ctx, rank, world, N=min(512, max(32, N // 2)), n_proj=720 if N >= 1024 else max(8, n_proj // 2))
@@ -363,6 +413,25 @@ def main():
         comm.close()
 
 
+def load_counters(fname, key, kernel, stale):
+    """One kernel's entry of a committed counter file (profiles/sq_counters.json, profiles/pmc_traffic.json) for the workload `key`,
+    or None: files hold {"source", "src_hash", "workloads": {key: {"workload", "kernels": {...}}}} (round 4; a round-3 file has one
+    "key" / "kernels" pair at the top).  Counters taken on other kernel sources are refused and named in `stale`."""
+    from tomography_alignment_amd import _lib
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        w = j["workloads"].get(key) if "workloads" in j else ({"kernels": j["kernels"]} if j.get("key") == key else None)
+        if w is None or kernel not in w["kernels"]:
+            return None, None
+        live_hash = _lib.kernel_source_hash()
+        if j.get("src_hash") != live_hash:
+            stale.append("profiles/%s (%s) was taken on kernel sources %s, this run has %s" % (fname, j.get("source", ""), j.get("src_hash"), live_hash))
+            return None, None
+        return w["kernels"][kernel], "profiles/%s (%s, workload %s, kernel sources %s)" % (fname, j.get("source", ""), key, live_hash)
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def make_roofline(name, ms_per_step, launches_per_step, alg_bytes_per_pass, key, useful_samples_per_pass=None, useful_sino_bytes=None):
     """Utilisation of every unit that could bound `name`, from counted work per launch (committed rocprofv3 PMC passes of this
     very command, profiles/sq_counters.json + profiles/pmc_traffic.json) and the live launch time; `bound` = the busiest unit.
@@ -376,31 +445,17 @@ def make_roofline(name, ms_per_step, launches_per_step, alg_bytes_per_pass, key,
     sq, pmc, write_bytes = None, None, None
     # Committed counters are used only for THIS workload (key) taken on THESE kernel sources (src_hash over csrc/*): counts of an
     # older kernel divided by the live time of a newer one would be a silent mix.
-    from tomography_alignment_amd import _lib
-    live_hash = _lib.kernel_source_hash()
     stale = []
-    try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))
-        if j.get("key") == key and name in j["kernels"]:
-            if j.get("src_hash") == live_hash:
-                sq = j["kernels"][name]
-                r["counters"] = {"source": "profiles/sq_counters.json (%s, kernel sources %s)" % (j.get("source", ""), live_hash), "per_pass": sq}
-            else:
-                stale.append("profiles/sq_counters.json (%s) was taken on kernel sources %s, this run has %s" % (j.get("source", ""), j.get("src_hash"), live_hash))
-    except (OSError, ValueError, KeyError):
-        pass
-    try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if j.get("key") == key and name in j["kernels"]:
-            if j.get("src_hash") == live_hash:
-                pmc = j["kernels"][name]["hbm_bytes_per_launch"]
-                write_bytes = j["kernels"][name].get("write_kb", 0.0) * 1024.0
-                r["traffic"] = pmc / launches_per_step
-                r["traffic_source"] = "profiles/pmc_traffic.json (%s, kernel sources %s)" % (j.get("source", ""), live_hash)
-            else:
-                stale.append("profiles/pmc_traffic.json (%s) was taken on kernel sources %s, this run has %s" % (j.get("source", ""), j.get("src_hash"), live_hash))
-    except (OSError, ValueError, KeyError):
-        pass
+    ent, src = load_counters("sq_counters.json", key, name, stale)
+    if ent is not None:
+        sq = ent
+        r["counters"] = {"source": src, "per_pass": sq}
+    ent, src = load_counters("pmc_traffic.json", key, name, stale)
+    if ent is not None:
+        pmc = ent["hbm_bytes_per_launch"]
+        write_bytes = ent.get("write_kb", 0.0) * 1024.0
+        r["traffic"] = pmc / launches_per_step
+        r["traffic_source"] = src
     if stale:
         r["stale_counters_refused"] = stale
     # useful arithmetic: every in-volume ray sample needs the four x,y-corner FMAs of its plane pair's bilinear weights = 8 flop in
@@ -430,6 +485,11 @@ def make_roofline(name, ms_per_step, launches_per_step, alg_bytes_per_pass, key,
             util["valu"] = (4.0 * sq["SQ_ACTIVE_INST_VALU"] / t / 1e9, N_CU * 4 * CLK_GHZ, "G SIMD-cycles/s")
         if sq.get("SQ_LDS_IDX_ACTIVE"):
             util["lds"] = (sq["SQ_LDS_IDX_ACTIVE"] / t / 1e9, N_CU * CLK_GHZ, "G LDS-cycles/s")
+    # The two HBM fractions side by side, at the top of the block (VERDICT r3 #2a): the SURVEY 8(d) figure -- algorithmic bytes (the
+    # volume re-read for every angle) / live time / 8 TB/s, which EXCEEDS 1 for a kernel that stages a tile once for all angles -- and
+    # what the HBM actually carried according to the counters (null without counters for this workload and these sources).
+    r["hbm_algorithmic_frac"] = round(alg_gbs / HBM_PEAK_GBS, 4)
+    r["hbm_counter_frac"] = round(pmc / t / 1e9 / HBM_PEAK_GBS, 4) if pmc is not None else None
     if not util:
         # no counters for this exact workload: fall back to the algorithmic-HBM figure, capped reading left to the consumer
         r.update({"bound": "hbm", "achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 4),
@@ -522,7 +582,9 @@ def align_rigid_e2e(ctx, N=512, n_proj=720, sirt_iters=10):
     loop on N^3 x n_proj with +-2 deg / +-5 px pose errors (default_rng(5), as align_rate): `sirt_iters` SIRT iterations with positivity
     at the nominal poses (device-resident solver), then ONE lock-step alignment pass (every projection's scipy L-BFGS-B on cost_xzab /
     gradient_xzab from a zero start, bounds +-6 px / +-0.05 rad, one fused cost+gradient launch per round of evaluations).  Wall
-    times include the host side (scipy, thread scheduling, staging); kernel times are HIP-event sums."""
+    times include the host side (scipy's L-BFGS-B steps, staging); kernel times are HIP-event sums.  Round 4: the alignment pass is
+    priced against a REPLAY of its own evaluations in full batches (`end_to_end_over_full_batch_replay`, 1 = nothing lost to batching
+    or to the host)."""
     from tomography_alignment_amd import _lib
     from tomography_alignment_amd.backend import HipBackend
     from tomography_alignment_amd.examples import align_rigid
@@ -544,11 +606,28 @@ def align_rigid_e2e(ctx, N=512, n_proj=720, sirt_iters=10):
     ctx.profile_reset()
     ctx.profile_enable(True)
     t0 = time.perf_counter()
-    _, a_rec, b_rec, xyz_rec, hist = align_rigid.run(data, n_outer=1, sirt_iters=sirt_iters, bounds=((-6., 6.), (-6., 6.), (-0.05, 0.05), (-0.05, 0.05)),
-                                                     verbose=False, backend=be)
+    trace = []
+    rec, a_rec, b_rec, xyz_rec, hist = align_rigid.run(data, n_outer=1, sirt_iters=sirt_iters, bounds=((-6., 6.), (-6., 6.), (-0.05, 0.05), (-0.05, 0.05)),
+                                                       verbose=False, backend=be, align_kwargs={"trace": trace})
     ctx.sync()
     wall = time.perf_counter() - t0
     ctx.profile_enable(False)
+    # The kernel rate the loop COULD have had: the very evaluations it made (same volume, same poses, same measured rows), replayed in
+    # launches of n_proj poses.  alignment_gradient.evals_per_sec is taken on another pose population (all 0.5 deg from the truth); the
+    # optimisers' own points run from untilted starts to tilts on the bounds, so only this replay prices the loop's batching + host side.
+    idx_all = np.concatenate([t[0] for t in trace])
+    poses_all = np.concatenate([t[1] for t in trace])
+    d_vol, d_tab = be.upload(np.asarray(rec, np.float32).ravel()), be.upload(np.asarray(data["projections"], np.float32).reshape(n_proj, -1))
+    be.cost_grad(np.ascontiguousarray(poses_all[:n_proj]), d_vol, d_tab, rows=idx_all[:n_proj])
+    ctx.set_option("reuse_staged_volume", 1)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for a in range(0, idx_all.size, n_proj):
+        be.cost_grad(np.ascontiguousarray(poses_all[a:a + n_proj]), d_vol, d_tab, rows=idx_all[a:a + n_proj])
+    ctx.sync()
+    replay_s = time.perf_counter() - t0
+    ctx.set_option("reuse_staged_volume", 0)
+    del d_vol, d_tab
     kms = {}
     for nm in names:
         n, ms = ctx.profile_get(nm)
@@ -561,6 +640,10 @@ def align_rigid_e2e(ctx, N=512, n_proj=720, sirt_iters=10):
             "sirt_kernel_s": round(sirt_ms / 1e3, 3), "alignment_kernel_s": round(kms.get("k_cost_grad", {}).get("ms", 0.0) / 1e3, 3),
             "alignment_evals": int(h["evals"]), "alignment_launches": int(h["launches"]),
             "evals_per_sec_end_to_end": round(h["evals"] / max(1e-9, h.get("align_wall_s", wall)), 1),
+            "evals_per_sec_kernels_in_loop": round(h["evals"] / max(1e-9, kms.get("k_cost_grad", {}).get("ms", 0.0) / 1e3), 1),
+            "evals_per_sec_same_evaluations_in_full_batches": round(idx_all.size / max(1e-9, replay_s), 1),
+            "end_to_end_over_full_batch_replay": round(replay_s / max(1e-9, h.get("align_wall_s", wall)), 3),
+            "driver": h.get("driver"),
             "sirt_wall_s": h.get("sirt_wall_s"), "align_wall_s": h.get("align_wall_s"),
             "shift_err_px": {"before": float(np.abs(xyz[:, [0, 2]]).mean()), "after": h["shift_err_px"]},
             "tilt_err_deg": {"before": float(np.rad2deg(np.abs(np.column_stack([alpha, beta])).mean())), "after": h["tilt_err_deg"]},

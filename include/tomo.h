@@ -250,6 +250,22 @@ TOMO_API int tomo_tv_norm_3d(tomo_ctx *ctx, const float *d_x, int nx, int ny, in
  * tomo_release_workspace frees it (synchronises the stream first).  The next call that needs it allocates it again. */
 TOMO_API int tomo_release_workspace(tomo_ctx *ctx);
 
+/* ---------------------------------------------------------------- array-level twins of the two f2py routines (csrc/tomo_f2py.hip)
+ * For a binding one level BELOW the operator API: utilities/ray_voxel_utilities.py:103,164 call
+ *   dat_inds, det_inds, wts, n_inds = ray_wt_grad.trilinear_ray_sparse(floor_points, w_floor, nx, ny, nz, n_rays, n_points)   src/ray_wt_grad.f90:1-92
+ *   det_img, grad_det_img = ray_wt_grad.trilinear_ray_interp(floor_points, w_floor, nx, ny, nz, n_rays, n_points, recon, step, der)   :95-223
+ * with sample tables built in numpy.  Same arguments here, as HOST arrays in the Fortran (column-major) layout f2py passes:
+ * floor_points int32 (3, n_rays, n_points), w_floor float64 (3, n_rays, n_points), recon float64 [nx*ny*nz], step float64
+ * (n_rays, n_points), der float64 (9, 3, n_rays); outputs det_img float64 [n_rays], grad_det_img float64 (6, n_rays) rows
+ * tx, ty, tz, phi, alpha, beta; dat_inds / det_inds int32 and wts float64 of length 8 * n_rays * n_points, pre-filled with -999 as the
+ * reference does (:15-17) and written in the reference's emission order, *h_n_inds = entries written.  float64 arithmetic in the
+ * reference's order.  The compatibility surface, not the fast path (36 bytes of table per sample). */
+TOMO_API int tomo_trilinear_ray_interp(tomo_ctx *ctx, const int32_t *h_floor_points, const double *h_w_floor, int nx, int ny, int nz, int n_rays,
+                              int n_points, const double *h_recon, const double *h_step, const double *h_der, double *h_det_img,
+                              double *h_grad_det_img);
+TOMO_API int tomo_trilinear_ray_sparse(tomo_ctx *ctx, const int32_t *h_floor_points, const double *h_w_floor, int nx, int ny, int nz, int n_rays,
+                              int n_points, int32_t *h_dat_inds, int32_t *h_det_inds, double *h_wts, int32_t *h_n_inds);
+
 /* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI)
  * Replaces mpi4py COMM_WORLD Allreduce(SUM) of recon/sirt_mpi.py:68,103 and recon/cgls_mpi.py:55,98
  * and the scalar allreduce of recon/sirt_mpi.py:110. */

@@ -734,3 +734,68 @@ def test_properties_at_full_size_1024():
     be.ctx.set_option("adj_flat_gather", 0)
     assert np.sqrt(be.diff_sumsq(be.adjoint(flat, y, tmp2), aty) / be.dot(aty, aty)) < 1e-6
     be.ctx.set_option("adj_flat_gather", 1)
+
+
+def _sample_tables(og, alpha, beta, phi, xyz, cor3):
+    """The (3, n_rays, n) tables the reference builds in numpy before it calls its f2py routines
+    (utilities/ray_voxel_utilities.py:85-99,151), from the oracle's restated ray set-up."""
+    from oracle import oracle as orc
+    p0, rhat, n, r_len0, src, det = orc.ray_setup(og, alpha, beta, phi, xyz, cor3)
+    n_rays = p0.shape[1]
+    r_points = np.zeros((3, n_rays, n))
+    r_points[:, :, :] = p0[:, :, np.newaxis]
+    step = np.zeros((n_rays, n))
+    for j in range(n):
+        r_points[:, :, j] += j * og.step_size * rhat
+        step[:, j] = j * og.step_size / r_len0
+    floor_points = np.floor(r_points).astype(np.int32)
+    w_floor = 1. - (r_points - floor_points.astype(np.float64))
+    der = orc.derivative_ray_points(src, (det - src)[:, 0], alpha, beta, phi, xyz)
+    return floor_points, w_floor, step, der, n_rays, n
+
+
+def test_f2py_signature_twins_vs_reference_golden(shepp32):
+    """VERDICT r3 "missing" #5: `src.ray_wt_grad.trilinear_ray_interp / trilinear_ray_sparse` with the f2py module's call signatures
+    (src/ray_wt_grad.f90:1-92,95-223; called at utilities/ray_voxel_utilities.py:103,164), on the library (csrc/tomo_f2py.hip):
+    fed with the sample tables the reference's Python builds, against the reference's own outputs -- G3 (`projection_gradient`, all
+    three generic poses; the degenerate one by value) and G1 b (the assembled CSR of generic poses with per-projection cor_shift) -- and against the oracle."""
+    from oracle import oracle as orc
+    from scipy import sparse
+    from tomography_alignment_amd.src import ray_wt_grad
+    g3 = golden("g3_proj_grad")
+    og = orc.Geo(1, np.array([32] * 3), np.ones(3), np.array([32, 32]), np.ones(2))
+    worst = 0.0
+    for i in range(4):
+        fp, wf, step, der, n_rays, n = _sample_tables(og, g3["alpha"][i], g3["beta"][i], g3["phi"][i], g3["xyz"][i], g3["cor"][i])
+        img, grad = ray_wt_grad.trilinear_ray_interp(np.asfortranarray(fp), np.asfortranarray(wf), 32, 32, 32, n_rays, n,
+                                                     np.asfortranarray(shepp32.ravel().astype(np.float64)), np.asfortranarray(step), np.asfortranarray(der))
+        assert img.shape == (n_rays,) and grad.shape == (6, n_rays) and img.dtype == np.float64
+        want_p, want_g = orc.projection_gradient(og, shepp32, g3["alpha"][i], g3["beta"][i], g3["phi"][i], g3["xyz"][i], g3["cor"][i], precision=np.float64)
+        if i == 3:      # degenerate pose (samples ON integer coordinates: a last-bit difference in a position flips a cell): the value only
+            assert rel_max(img, want_p) < 1e-9 and rel_max(img, g3["proj"][i]) < 2e-7
+            continue
+        e_o = max(rel_max(img, want_p), rel_max(grad, want_g))
+        e_r = max(rel_max(img, g3["proj"][i]), rel_max(grad, g3["grad"][i]))       # the reference's outputs (stored in its `precision`, float32)
+        worst = max(worst, e_o)
+        assert e_o < 1e-11 and e_r < 2e-7, (i, e_o, e_r)
+    # trilinear_ray_sparse: G1 b, per projection -> COO -> the reference's CSR (duplicates summed), and the raw emission order vs the oracle
+    g1 = golden("g1_operator")
+    N = 8
+    n_proj = len(g1["b_phi"])
+    og = orc.Geo(n_proj, np.array([N] * 3), np.ones(3), np.array([N, N]), np.ones(2), cor_shift=g1["b_cor"])
+    rows, cols, vals = [], [], []
+    for ip in range(n_proj):
+        fp, wf, step, der, n_rays, n = _sample_tables(og, g1["b_alpha"][ip], g1["b_beta"][ip], g1["b_phi"][ip], g1["b_xyz"][ip], g1["b_cor"][ip])
+        dat, det, wts, n_inds = ray_wt_grad.trilinear_ray_sparse(np.asfortranarray(fp), np.asfortranarray(wf), N, N, N, n_rays, n)
+        assert dat.shape == (8 * n_rays * n,) and dat.dtype == np.int32 and wts.dtype == np.float64
+        assert np.all(dat[n_inds:] == -999) and np.all(det[n_inds:] == -999) and np.all(wts[n_inds:] == -999.0)      # src/ray_wt_grad.f90:15-17
+        o_dat, o_det, o_wts = orc.forward_sparse(og, g1["b_alpha"][ip], g1["b_beta"][ip], g1["b_phi"][ip], g1["b_xyz"][ip], g1["b_cor"][ip])
+        assert n_inds == o_dat.size and np.array_equal(dat[:n_inds], o_dat) and np.array_equal(det[:n_inds], o_det) and np.allclose(wts[:n_inds], o_wts, rtol=1e-11, atol=1e-15)
+        rows.append(det[:n_inds].astype(np.int64) + ip * n_rays)
+        cols.append(dat[:n_inds].astype(np.int64))
+        vals.append(wts[:n_inds])
+    A = sparse.csr_matrix(sparse.coo_matrix((np.concatenate(vals).astype(np.float32), (np.concatenate(rows), np.concatenate(cols))), shape=tuple(g1["b_shape"])))
+    A.sum_duplicates()
+    A.sort_indices()
+    assert np.array_equal(A.indptr, g1["b_indptr"]) and np.array_equal(A.indices, g1["b_indices"]) and rel_max(A.data, g1["b_data"]) < 1e-6
+    print("f2py twins: trilinear_ray_interp vs the float64 oracle %.1e; trilinear_ray_sparse reproduces G1 b's CSR" % worst)

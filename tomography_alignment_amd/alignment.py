@@ -4,9 +4,13 @@ Batched per-projection pose alignment: the inner loop of the reference's example
 optimisers advancing together, so that each round of function evaluations is ONE launch of the fused
 cost/gradient kernel over many projections (tomo_cost_grad) instead of n_proj separate launches.
 
-scipy's L-BFGS-B is kept as the optimiser (drop-in semantics): a fixed pool of worker threads each runs one projection's
-`optimize.minimize` at a time; an evaluation request blocks until the scheduler has collected the pending
-requests of the live workers, evaluated them in one batch and handed the results back.
+scipy's L-BFGS-B is kept as the optimiser (drop-in semantics, identical iterates).  Round 4: its compiled core is driven in reverse
+communication for all projections from ONE Python thread (_lbfgsb_batch.py): the live optimisers are two populations that take
+turns -- while the GPU evaluates one (a helper thread sits in the ctypes call, the GIL released), this thread runs the other's
+optimiser steps; the few optimisers of the tail run as one population.  Where this scipy's private core does not have the
+expected layout (or `driver="threads"`), round 3's form runs instead: a fixed pool of worker threads each runs one projection's
+`optimize.minimize` at a time; an evaluation request blocks until the scheduler has collected the pending requests of the live
+workers, evaluated them in one batch and handed the results back (a third of the wall time went to thread hand-overs).
 
 Multi-GPU: projections are independent -- rank r aligns np.array_split(arange(n_proj), P)[r] with a
 replicated volume and no collective inside the optimiser; the 4 recovered parameters per projection are gathered
@@ -20,9 +24,20 @@ import numpy as np
 from scipy import optimize
 
 try:
-    from . import _lib
+    from . import _lib, _lbfgsb_batch
 except ImportError:
     import _lib
+    import _lbfgsb_batch
+
+_BATCH_OK = None
+
+
+def batch_driver_available():
+    """The reverse-communication driver reproduces scipy.optimize.minimize bit for bit on this scipy (checked once)?"""
+    global _BATCH_OK
+    if _BATCH_OK is None:
+        _BATCH_OK = bool(_lbfgsb_batch.AVAILABLE and _lbfgsb_batch.self_test())
+    return _BATCH_OK
 
 # parameter letters -> pose columns (phi, alpha, beta, tx, ty, tz, cor_x) and Jacobian rows (tx,ty,tz,phi,alpha,beta)
 _POSE_COL = {"x": 3, "y": 4, "z": 5, "p": 0, "a": 1, "b": 2}
@@ -32,8 +47,9 @@ _GRAD_ROW = {"x": 0, "y": 1, "z": 2, "p": 3, "a": 4, "b": 5}
 class BatchEvaluator(object):
     """cost / gradient of many projections per launch, volume and measured projections resident in HBM."""
 
-    def __init__(self, backend, rec, projections, cor_shift=None):
+    def __init__(self, backend, rec, projections, cor_shift=None, trace=None):
         self.be = backend
+        self.trace = trace      # a list: every launch's (projection indices, poses) is appended (bench.py replays them in full batches)
         self.vol = rec if backend.is_buffer(rec) else backend.upload(np.asarray(rec, np.float32).ravel())
         b = np.asarray(projections, np.float32)
         self.n = b.shape[0]
@@ -53,6 +69,8 @@ class BatchEvaluator(object):
         poses[:, 6] = self.cor[idx]
         self.n_launch += 1
         self.n_eval += m
+        if self.trace is not None:
+            self.trace.append((idx.copy(), poses.copy()))
         t0 = time.perf_counter()
         out = self.be.cost_grad(np.ascontiguousarray(poses), self.vol, self._b_all, rows=idx)   # measured rows stay in HBM
         if not self._staged:                    # self.vol is pinned until close(): its zero-padded copy is staged once
@@ -150,7 +168,7 @@ class _Scheduler(object):
 
 
 def align_projections(backend, rec, projections, phi, letters="xzab", x0=None, angles0=None, xyz0=None, cor_shift=None,
-                      bounds=None, scale_factor=None, options=None, indices=None, max_threads=256):
+                      bounds=None, scale_factor=None, options=None, indices=None, max_threads=256, driver="auto", trace=None):
     """Align many projections at once.
 
     letters   which pose components are free, reference naming (utilities/alignment_functions.py): "xzab" = tx, tz,
@@ -174,10 +192,34 @@ def align_projections(backend, rec, projections, phi, letters="xzab", x0=None, a
     if xyz0 is not None:
         base[:, 3:6] = np.asarray(xyz0, np.float64)
     x0 = np.zeros((n_all, k)) if x0 is None else np.asarray(x0, np.float64).reshape(n_all, k)
-    ev = BatchEvaluator(backend, rec, b, cor_shift)
+    ev = BatchEvaluator(backend, rec, b, cor_shift, trace=trace)
     out_x, out_f, out_n = np.zeros((n_all, k)), np.zeros(n_all), np.zeros(n_all, np.int64)
     opts = {"disp": False}
     opts.update(options or {})
+
+    if driver == "batch" and not batch_driver_available():
+        raise _lib.TomoError("align_projections: the reverse-communication L-BFGS-B driver does not match this scipy")
+    if driver != "threads" and batch_driver_available():
+        # ---- round 4: every optimiser in this thread, two populations taking turns on the device (see the module docstring)
+        from concurrent.futures import ThreadPoolExecutor
+        order = np.asarray(indices, np.int64)
+
+        def fun_batch(ids, X):
+            sel = order[np.asarray(ids, np.int64)]
+            poses = base[sel].copy()
+            poses[:, cols] += X
+            cost, g6 = ev.evaluate(sel, poses)
+            return cost, g6[:, rows] * scale
+
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            try:
+                x, f, nf, _ = _lbfgsb_batch.minimize_many(fun_batch, x0[order], bounds=bounds, options=opts, overlap=pool.submit)
+            finally:
+                ev.close()
+        out_x[order], out_f[order], out_n[order] = x, f, nf
+        return {"x": out_x, "fun": out_f, "nfev": out_n, "n_launch": ev.n_launch, "n_eval": ev.n_eval, "t_eval": ev.t_eval,
+                "driver": "batch", "wall_s": time.perf_counter() - t0}
 
     # a fixed pool of worker threads (at most max_threads): each runs one projection's optimiser at a time and takes the next
     # projection from the queue when it converges, so the batches stay full until the very end instead of draining once per
@@ -230,7 +272,7 @@ def align_projections(backend, rec, projections, phi, letters="xzab", x0=None, a
         sys.setswitchinterval(switch)
     if errors:
         raise errors[0]
-    return {"x": out_x, "fun": out_f, "nfev": out_n, "n_launch": ev.n_launch, "n_eval": ev.n_eval, "t_eval": ev.t_eval}
+    return {"x": out_x, "fun": out_f, "nfev": out_n, "n_launch": ev.n_launch, "n_eval": ev.n_eval, "t_eval": ev.t_eval, "driver": "threads"}
 
 
 def align_projections_sharded(comm, backend, rec, projections, phi, **kw):

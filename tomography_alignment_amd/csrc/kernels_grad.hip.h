@@ -364,6 +364,11 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
     const uint32_t sy4 = (uint32_t)g.nzp * 4u, sx4 = (uint32_t)g.nyp * (uint32_t)g.nzp * 4u;     // < 2^23 (tomo_check_geometry): signed 24-bit multiplies
     const uint32_t abias4 = tomo_abias_bytes(sx4, sy4) + tomo_lbias_bytes(sx4, sy4);
     const float sfs = (float)(g.step / c.rlen);
+#if defined(TOMO_ABLATE_GRAD_LOADS) && TOMO_ABLATE_GRAD_LOADS == 1
+    __shared__ float abl_lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += 256) abl_lds[i] = vp[i];
+    __syncthreads();
+#endif
     double val = 0.0, s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
     for (int jb = J0; jb < J1; jb += TOMO_JB) {
         int ia[3];
@@ -398,6 +403,17 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
         // issue: addresses, the four gathers, and -- decided from the addresses alone -- the fallback gathers.
         // (Macros over plain scalars on purpose: a struct passed to helper lambdas was promoted to an LDS alloca, which put
         // a store of every loaded value -- hence a vmcnt(0) wait -- between the two samples' loads.)
+        // TOMO_ABLATE_GRAD_LOADS (timing experiments only, results are wrong by construction; profiles/round4_grad_lds_ablation.md):
+        // 1 = every gather becomes an LDS read of a resident 32 KB array at an address derived from the gather's own -- what an
+        //     LDS-staged form of this kernel could reach at best, with staging, halos and ownership for free;
+        // 2 = no loads at all (a value made from the address bits): the floor set by the kernel's VALU work.
+#if defined(TOMO_ABLATE_GRAD_LOADS) && TOMO_ABLATE_GRAD_LOADS == 1
+#define GS_LOAD(base, off) abl_lds[((uint32_t)(uintptr_t)(base) + (off)) >> 2 & 8191u]
+#elif defined(TOMO_ABLATE_GRAD_LOADS) && TOMO_ABLATE_GRAD_LOADS == 2
+#define GS_LOAD(base, off) __uint_as_float(0x3f800000u | ((uint32_t)(uintptr_t)(base) + (off) & 0x7fffffu))
+#else
+#define GS_LOAD(base, off) (*(const float *)((base) + (off)))
+#endif
 #define GS_DECL(S) float S##v000, S##v010, S##v100, S##v110, S##f001, S##f011, S##f101, S##f111, S##wx, S##wy, S##wz, S##t; /* f*: set, and selected, only where fb */ \
                    unsigned long long S##actm, S##fbm /* lane masks: the sample is the lane's own; it loads its own upper corners */
 #define GS_ISSUE(S, JJ)                                                                                                            \
@@ -409,16 +425,16 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
         S##wx = fract_f32(x); S##wy = fract_f32(y); S##wz = fract_f32(z);                                                          \
         const uint32_t vo_own = off0 + (uint32_t)__mul24(cvt_floor_i32(x), (int)sx4) + (uint32_t)__mul24(cvt_floor_i32(y), (int)sy4) + ((uint32_t)cvt_floor_i32(z) << 2); \
         const uint32_t vo = has ? vo_own : borrow;                                                                                 \
-        S##v000 = *(const float *)(sb00 + vo); S##v010 = *(const float *)(sb01 + vo);                                              \
-        S##v100 = *(const float *)(sb10 + vo); S##v110 = *(const float *)(sb11 + vo);                                              \
+        S##v000 = GS_LOAD(sb00, vo); S##v010 = GS_LOAD(sb01, vo);                                                                  \
+        S##v100 = GS_LOAD(sb10, vo); S##v110 = GS_LOAD(sb11, vo);                                                                  \
         const uint32_t nb = (uint32_t)dpp_shl1_i((int)vo); /* lane 63 receives 0: never vo + 4 */                                 \
         const uint32_t vo4 = vo + 4u;                                                                                              \
         const bool fb = has && jc == (JJ) && nb != vo4;                                                                            \
         S##fbm = S##actm & __builtin_amdgcn_ballot_w64(nb != vo4);                                                                 \
         asm("" : "=v"(S##f001), "=v"(S##f011), "=v"(S##f101), "=v"(S##f111)); /* defined (no instruction); only fb lanes' values are selected */ \
         if (fb) { /* my upper-z cell is not the neighbour's lower-z cell */                                                        \
-            S##f001 = *(const float *)(sb00 + vo4); S##f011 = *(const float *)(sb01 + vo4);                                        \
-            S##f101 = *(const float *)(sb10 + vo4); S##f111 = *(const float *)(sb11 + vo4);                                        \
+            S##f001 = GS_LOAD(sb00, vo4); S##f011 = GS_LOAD(sb01, vo4);                                                            \
+            S##f101 = GS_LOAD(sb10, vo4); S##f111 = GS_LOAD(sb11, vo4);                                                            \
         }                                                                                                                          \
     }
         // consume: the shifts run with every lane enabled (a DPP source lane that is masked off delivers nothing): take them
@@ -460,6 +476,7 @@ __global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ 
             av += qv; a0x += q0x; a0y += q0y; a0z += q0z; a1x += q1x; a1y += q1y; a1z += q1z;
         }
 #undef GS_DECL
+#undef GS_LOAD
 #undef GS_ISSUE
 #undef GS_CONSUME
         val += (double)av;

@@ -17,7 +17,7 @@ from ..recon import sirt
 from ..utilities import geometry
 
 
-def run(data, n_outer=5, sirt_iters=50, bounds=((-3., 3.), (-3., 3.), (-0.02, 0.02), (-0.02, 0.02)), verbose=True, backend=None):
+def run(data, n_outer=5, sirt_iters=50, bounds=((-3., 3.), (-3., 3.), (-0.02, 0.02), (-0.02, 0.02)), verbose=True, backend=None, align_kwargs=None):
     proj = np.asarray(data["projections"], np.float32)
     phi = np.asarray(data["phi"], np.float64)
     ground_truth = data["phantom"] if "phantom" in data else None
@@ -38,11 +38,11 @@ def run(data, n_outer=5, sirt_iters=50, bounds=((-3., 3.), (-3., 3.), (-0.02, 0.
         solver = sirt.SIRT(geom, proj.reshape(n_proj, -1), np.array([phi, alpha_rec, beta_rec]).T, xyz_rec, options=opts)
         rec, err = solver.run_main_iteration(niter=sirt_iters, positivity=True)
         t1 = time.perf_counter()
-        res = alignment.align_projections(solver.be, solver.d_rec, proj.reshape(n_proj, -1), phi, letters="xzab", bounds=bounds)
+        res = alignment.align_projections(solver.be, solver.d_rec, proj.reshape(n_proj, -1), phi, letters="xzab", bounds=bounds, **(align_kwargs or {}))
         t2 = time.perf_counter()
         xyz_rec[:, 0], xyz_rec[:, 2] = res["x"][:, 0], res["x"][:, 1]
         alpha_rec, beta_rec = res["x"][:, 2].copy(), res["x"][:, 3].copy()
-        entry = {"outer": it, "rmse": float(err[-1]), "residual": float(res["fun"].sum()), "launches": res["n_launch"], "evals": res["n_eval"],
+        entry = {"outer": it, "rmse": float(err[-1]), "residual": float(res["fun"].sum()), "launches": res["n_launch"], "evals": res["n_eval"], "driver": res.get("driver"),
                  "sirt_wall_s": round(t1 - t0, 3), "align_wall_s": round(t2 - t1, 3)}
         if "xyz" in data:
             entry["shift_err_px"] = float(np.abs(xyz_rec[:, [0, 2]] - np.asarray(data["xyz"])[:, [0, 2]]).mean())

@@ -25,7 +25,7 @@ class CGLS(object):
         self.ground_truth = options['ground_truth'] if 'ground_truth' in options else None
         self.rec = options['rec'] if 'rec' in options else None
         if self.rec is None:
-            self.rec = np.zeros((int(self.geometry.n_vox),), dtype=np.asarray(self.projections).dtype)
+            self.rec = np.zeros((int(self.geometry.n_vox),), dtype=getattr(self.projections, 'dtype', np.float32))
         self.precision = options['precision'] if 'precision' in options else np.float32
         self._backend = options.get('_backend')
         self.rms_error = None
@@ -57,7 +57,11 @@ class CGLS(object):
         n_vox, n_rows = be.n_vox, rows.size * be.n_det
         if self._bufs is None:
             self._bufs = True
-            self.d_b = be.upload(np.asarray(self.projections, np.float32).reshape(self.n_proj, -1)[rows])
+            if be.is_buffer(self.projections):          # already in HBM (this rank's rows): no PCIe traffic (bench.py at 1024^3)
+                self.d_b = self.projections
+            else:
+                self.d_b = be.upload(np.asarray(self.projections, np.float32).reshape(self.n_proj, -1)[rows])
+            self.d_tmp = be.empty(n_rows)               # A rec of the ||b - A rec|| test (recon/cgls.py:58-59), kept across iterations
             self.d_rec = be.upload(np.asarray(self.rec, np.float32).ravel())
             self.d_r = be.empty(n_rows)
             self.d_q = be.empty(n_rows)
@@ -69,10 +73,18 @@ class CGLS(object):
         self._allreduce_vol(self.proj_mat.T.apply(self.d_r, self.d_p))       # _p = A^T _r           :34 ; cgls_mpi.py:55
         self._gamma = be.dot(self.d_p, self.d_p)                             # ||_p||^2              :36
 
-    def run_main_iteration(self, make_plot=False, niter=100, debug=False):
+    def iterate_device(self, niter=100):
+        """run_main_iteration without the final download: `self.d_rec` holds the reconstruction; returns (k, rms_error[:k])."""
+        rec, rms = self.run_main_iteration(niter=niter, _download=False)
+        return len(rms), rms
+
+    def run_main_iteration(self, make_plot=False, niter=100, debug=False, _download=True):
         be = self.be
         if self.ground_truth is None:
-            norm_factor = np.linalg.norm(np.asarray(self.projections, np.float32))
+            if be.is_buffer(self.projections):
+                norm_factor = np.sqrt(self._allreduce_scalar(be.dot(self.d_b, self.d_b)))
+            else:
+                norm_factor = np.linalg.norm(np.asarray(self.projections, np.float32))
         else:
             norm_factor = np.linalg.norm(self.ground_truth)
         k, reinit_iter = 0, 0
@@ -87,7 +99,7 @@ class CGLS(object):
                 print('reinitializing at iteration %d' % k)
                 if reinit_iter + 1 == k:
                     print('need to re-initialize at two consecutive iterations: quitting')
-                    self.rec = be.download(self.d_rec)
+                    self.rec = be.download(self.d_rec) if _download else self.rec
                     return self.rec, self.rms_error[:k]
                 be.axpy(self.d_rec, self.d_p, -alpha)                                        # :66
                 q_keep = be.empty(self.d_q.size)
@@ -106,12 +118,11 @@ class CGLS(object):
             else:
                 self.rms_error[k] = np.sqrt(be.diff_sumsq(self.d_rec, self.d_gt)) / norm_factor                # :82
             k += 1
-        self.rec = be.download(self.d_rec)
+        self.rec = be.download(self.d_rec) if _download else self.rec
         return self.rec, self.rms_error[:k]
 
     def _conv_sumsq(self):
         """||b - A rec||^2 (recon/cgls.py:58-59); costs one extra forward projection, as in the reference."""
         be = self.be
-        tmp = be.empty(self.d_q.size)
-        self.proj_mat.apply(self.d_rec, tmp)
-        return be.diff_sumsq(self.d_b, tmp)
+        self.proj_mat.apply(self.d_rec, self.d_tmp)
+        return be.diff_sumsq(self.d_b, self.d_tmp)

@@ -38,6 +38,22 @@ def find(d, pat):
     return m[0] if m else None
 
 
+def merge_counters(path, tag, key, workload, kernels):
+    """Counter files hold several workloads taken on ONE set of kernel sources: {"source", "src_hash", "workloads": {key: {"workload",
+    "kernels"}}}.  A file of other sources (or of the round-3 single-workload layout) is replaced, one of the same sources is added to."""
+    h = _src_hash()
+    j = {}
+    try:
+        j = json.load(open(path))
+    except (OSError, ValueError):
+        pass
+    if j.get("src_hash") != h or "workloads" not in j:
+        j = {"source": tag, "src_hash": h, "workloads": {}}
+    j["source"] = tag.split("_")[0] if j["workloads"] else tag
+    j["workloads"][key] = {"workload": workload, "source": tag, "kernels": kernels}
+    json.dump(j, open(path, "w"), indent=1)
+
+
 def pmc(d, name):
     """kernel -> per-dispatch totals of counter `name`, in dispatch order"""
     out = {}
@@ -101,7 +117,7 @@ def main():
             lines.append("| `%s` | %.4g | %.4g | %.4g |" % (k, f, w, b))
     open(os.path.join(a.out, a.tag + "_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
     if traffic:
-        json.dump({"workload": a.workload, "key": a.key, "source": a.tag, "src_hash": _src_hash(), "kernels": traffic}, open(os.path.join(a.out, "pmc_traffic.json"), "w"), indent=1)
+        merge_counters(os.path.join(a.out, "pmc_traffic.json"), a.tag, a.key, a.workload, traffic)
     print("\n".join(lines))
 
 

@@ -16,7 +16,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from summarise_rocprof import short, _src_hash  # noqa: E402
+from summarise_rocprof import short, _src_hash, merge_counters  # noqa: E402,F401
 
 LDS_BYTES_PER_INSTR = {"k_fwd_tile_flat": 512, "k_adj_gather_flat": 256, "k_fwd_tile": 512, "k_adj_tile": 256, "k_adj_tile_flat": 256}
 
@@ -52,7 +52,7 @@ def main():
         kernels[k] = merged
         lines += ["## `%s`" % k, "", "| counter | per launch |", "|---|---|"] + ["| `%s` | %.6g |" % (n, v) for n, v in sorted(merged.items())] + [""]
     os.makedirs(a.out, exist_ok=True)
-    json.dump({"workload": a.workload, "key": a.key, "source": a.tag, "src_hash": _src_hash(), "kernels": kernels}, open(os.path.join(a.out, "sq_counters.json"), "w"), indent=1)
+    merge_counters(os.path.join(a.out, "sq_counters.json"), a.tag, a.key, a.workload, kernels)
     open(os.path.join(a.out, a.tag + "_sq_counters.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
