@@ -36,6 +36,14 @@ def shepp32():
     return golden("g7_phantom")["shepp32"]
 
 
+# Face-distance threshold of the GPU tests' per-ray gradient exemption (voxels).  Rounds 2-3 used 2e-5 (6 % of the rays at 512^3); round 4
+# MEASURED what the mask hides (tests/test_gpu_configs.py prints it): of ~15 700 masked rays per pose 0-3 actually flip sides, the
+# farthest 6.2e-7 voxel from its face -- the kernels' in-block float32 positions are good to 1.3e-6 voxel (tools/grad_error_model.py).
+# 4e-6 keeps a 3x margin on that and exempts 1.2 % of the rays.  (The reference's OWN float32 routine needs more: its plain float32
+# positions flip rays up to 2.8e-6 from a face at 64^3 already -- test_oracle_golden.py keeps 2e-5 for it.)
+FACE_TOL_KERNELS = 4e-6
+
+
 def g10_case():
     """Golden G10 (tests/golden/make_golden.py::g10): the volume is regenerated from its seed and checked against the stored
     checksum; returns (g, x float64 [N,N,N], grad32 in the Python API's row order tx, ty, tz, phi, alpha, beta)."""

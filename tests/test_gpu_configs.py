@@ -13,7 +13,7 @@ import time
 import numpy as np
 import pytest
 
-from conftest import rel_max, rel_l2
+from conftest import rel_max, rel_l2, FACE_TOL_KERNELS
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -107,10 +107,10 @@ def c5():
 
 def test_config5_projection_gradient_512_all_variants(c5, capsys):
     """Per-ray projection and 6-DoF gradient at 512^3, +-2 deg / +-5 px: every kernel variant against the float64 oracle.
-    Value: all rays, 1e-5.  Gradient rows: 1e-5 of the row's maximum on every ray whose samples all keep >= 2e-5 voxel from
-    a cell face -- across a face the interpolant's value is continuous but its spatial gradient jumps (by the local second
+    Value: all rays, 1e-5.  Gradient rows: 1e-5 of the row's maximum on every ray whose samples all keep >= 4e-6 voxel
+    (conftest.FACE_TOL_KERNELS; 2e-5 until round 3) from a cell face -- across a face the interpolant's value is continuous but its spatial gradient jumps (by the local second
     difference: O(1) on the piecewise-constant phantom), so a sample within the kernels' float32 position rounding
-    (<= 6e-6 voxel) of a face may legitimately sit on the other side."""
+    (<= 1.3e-6 voxel, tools/grad_error_model.py) of a face may legitimately sit on the other side."""
     be, N, n_det = c5["be"], c5["N"], c5["N"] ** 2
     pr, gd = be.empty(n_det), be.empty(6 * n_det)
     rows, masked = [], []
@@ -121,7 +121,7 @@ def test_config5_projection_gradient_512_all_variants(c5, capsys):
             be.proj_grad(np.ascontiguousarray(c5["poses"][k:k + 1]), c5["vol"], pr, gd, 0)
             p, g = pr.download(), gd.download().reshape(6, n_det)
             per_variant[v, k] = (p, g)
-            ok = fd > 2e-5
+            ok = fd > FACE_TOL_KERNELS
             e_p = rel_max(p, p0)
             # rows of one unit are measured against the largest of them (translations tx, ty, tz; angles phi, alpha, beta): the
             # translation along the beam telescopes to ~0 along a ray (f(exit) - f(entry)), so its own maximum is no yardstick
@@ -142,23 +142,23 @@ def test_config5_projection_gradient_512_all_variants(c5, capsys):
         print("\n[C5 512^3] oracle (3 poses, %d threads): %.0f s" % (_threads(), c5["t_oracle"]))
         for v, k, e_p, e_g, e_g_all, frac, own in rows:
             print("[C5 512^3] grad_variant %d pose %d: proj rel-max %.2e | grad rel-max %.2e on well-conditioned rays (%.1f %% of rays "
-                  "within 2e-5 voxel of a cell face excluded; all rays: %.2e) | each row against its own max: %s"
+                  "within 4e-6 voxel of a cell face excluded; all rays: %.2e) | each row against its own max: %s"
                   % (v, c5["pick"][k], e_p, e_g, 100 * frac, e_g_all, " ".join("%.1e" % x for x in own)))
         for v, k, n_masked, n_flips, fd_max, med in masked:
             print("[C5 512^3] grad_variant %d pose %d: of the %d masked rays (%.1f %% of %d) %d deviate by >= 1e-5 (%.2f %% of all rays; the farthest "
                   "of them %.1e voxel from a face), the others agree -- median deviation of a masked ray %.1e"
                   % (v, c5["pick"][k], n_masked, 100.0 * n_masked / n_det, n_det, n_flips, 100.0 * n_flips / n_det, fd_max, med))
     for v, k, e_p, e_g, e_g_all, frac, own in rows:
-        assert e_p < TOL and e_g < TOL and frac < 0.10, (v, k, e_p, e_g, frac)
+        assert e_p < TOL and e_g < TOL and frac < 0.02, (v, k, e_p, e_g, frac)
     for v, k, n_masked, n_flips, fd_max, med in masked:
-        # the mask is 2e-5 voxel wide as a MARGIN; what actually flips sides lies within the kernels' position rounding of a face and is
+        # the mask is 4e-6 voxel wide as a MARGIN; what actually flips sides lies within the kernels' position rounding of a face and is
         # a small fraction of the masked rays, whose median deviation is that of an ordinary ray
-        assert n_flips <= 0.25 * n_masked and fd_max < 1e-5 and med < TOL, (v, k, n_masked, n_flips, fd_max, med)
+        assert n_flips <= 0.05 * n_masked and fd_max < 2e-6 and med < TOL, (v, k, n_masked, n_flips, fd_max, med)
     # variants 2-4 walk the same wave-uniform sample blocks (same float32 positions, same cell for every sample): identical sums
     # on every ray; variant 1 anchors its blocks per ray, so a sample ON a cell face may fall on the other side -- compared on
     # the well-conditioned rays only
     for k in range(3):
-        ok = c5["ref"][k][2] > 2e-5
+        ok = c5["ref"][k][2] > FACE_TOL_KERNELS
         assert rel_max(per_variant[3, k][1], per_variant[2, k][1]) < 2e-6 and rel_max(per_variant[3, k][0], per_variant[2, k][0]) < 2e-6
         assert rel_max(per_variant[2, k][0], per_variant[1, k][0]) < 5e-6
         assert rel_max(per_variant[2, k][1][:, ok], per_variant[1, k][1][:, ok]) < 5e-6
