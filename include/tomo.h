@@ -117,6 +117,9 @@ TOMO_API int tomo_sync(tomo_ctx *ctx);
  *   "comm_test_poison_us" n (tests only): every asynchronous collective first doubles its buffer, idles n microseconds and halves it
  *                 again on the communication stream, so that a compute-stream kernel that did not wait for it is caught by a
  *                 one-rank run; default 0 */
+/* HIP's current device is per thread: a thread other than the context's creator calls this once before it uses the context
+ * (entry points that need a geometry also do it themselves).  One context must still not be used by two threads at the same time. */
+TOMO_API int tomo_ctx_make_current(tomo_ctx *ctx);
 TOMO_API int tomo_set_option(tomo_ctx *ctx, const char *key, int value);
 
 /* Geometry: replaces passing a `Geometry` object to utilities/ray_voxel_utilities.py:53,113.

@@ -799,3 +799,28 @@ def test_f2py_signature_twins_vs_reference_golden(shepp32):
     A.sort_indices()
     assert np.array_equal(A.indptr, g1["b_indptr"]) and np.array_equal(A.indices, g1["b_indices"]) and rel_max(A.data, g1["b_data"]) < 1e-6
     print("f2py twins: trilinear_ray_interp vs the float64 oracle %.1e; trilinear_ray_sparse reproduces G1 b's CSR" % worst)
+
+
+def test_context_used_from_a_helper_thread(PM, orc, shepp32):
+    """HIP's current device is per thread: a context created in one thread and used from another (alignment.py evaluates its batches from a
+    helper thread) binds the thread with tomo_ctx_make_current; entry points that need a geometry do it themselves.  Same results either way."""
+    import threading
+    from tomography_alignment_amd import _lib
+    geo, og = geo_pair(2, 32)
+    P = PM(geo)
+    be = P.backend
+    poses = _lib.poses_array(np.array([0.4, 1.9]), np.array([0.01, -0.02]), np.array([-0.015, 0.01]), np.array([[0.5, 0., -1.], [-1.5, 0., 0.7]]), np.zeros(3))
+    vol = be.upload(shepp32)
+    want = be.forward(poses, vol, be.empty(2 * 1024)).download()
+    got = {}
+
+    def work():
+        be.ctx.make_current()
+        d = be.upload(shepp32)                      # allocation + copy + launch + download, all from this thread
+        got["fwd"] = be.forward(poses, d, be.empty(2 * 1024)).download()
+        got["cg"] = be.cost_grad(poses, d, be.upload(want))
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert np.array_equal(got["fwd"], want)
+    assert np.all(got["cg"][0] < 1e-6 * np.sum(want.astype(np.float64) ** 2))       # cost of the exact projections ~ 0

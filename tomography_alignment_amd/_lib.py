@@ -50,6 +50,7 @@ SIGNATURES = {
     "tomo_memcpy_d2d": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_size_t]),
     "tomo_memset0": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_size_t]),
     "tomo_sync": (ctypes.c_int, [_c_vp]),
+    "tomo_ctx_make_current": (ctypes.c_int, [_c_vp]),
     "tomo_set_option": (ctypes.c_int, [_c_vp, ctypes.c_char_p, ctypes.c_int]),
     "tomo_check_geometry": (ctypes.c_int, [ctypes.POINTER(TomoGeom), ctypes.POINTER(ctypes.c_int)]),
     "tomo_set_geometry": (ctypes.c_int, [_c_vp, ctypes.POINTER(TomoGeom)]),
@@ -195,6 +196,10 @@ class Context(object):
 
     def set_option(self, key, value):
         self.check(self.lib.tomo_set_option(self.handle, key.encode(), int(value)))
+
+    def make_current(self):
+        """Bind the CALLING thread to this context's GPU (HIP's current device is per thread; a new thread starts on device 0)."""
+        self.check(self.lib.tomo_ctx_make_current(self.handle))
 
     # ---- memory
     def empty(self, shape, dtype=np.float32):

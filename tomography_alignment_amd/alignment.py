@@ -212,7 +212,9 @@ def align_projections(backend, rec, projections, phi, letters="xzab", x0=None, a
             return cost, g6[:, rows] * scale
 
         t0 = time.perf_counter()
-        with ThreadPoolExecutor(max_workers=1) as pool:
+        ctx = getattr(backend, "ctx", None)
+        # the helper thread is the only one that touches the GPU while the pass runs; HIP's current device is per thread
+        with ThreadPoolExecutor(max_workers=1, initializer=(ctx.make_current if ctx is not None else None)) as pool:
             try:
                 x, f, nf, _ = _lbfgsb_batch.minimize_many(fun_batch, x0[order], bounds=bounds, options=opts, overlap=pool.submit)
             finally:

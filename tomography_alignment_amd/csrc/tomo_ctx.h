@@ -116,6 +116,7 @@ void tomo_prof_end_on(tomo_ctx *ctx, hipStream_t stream);
     do {                                                                                 \
         if (!(ctx)) return tomo_fail(nullptr, TOMO_ERR_ARG, "null ctx");                 \
         if (!(ctx)->has_geom) return tomo_fail((ctx), TOMO_ERR_STATE, "geometry not set"); \
+        (void)hipSetDevice((ctx)->device);   /* the current device is per THREAD: a caller's helper thread starts on device 0 */ \
     } while (0)
 
 // launch with optional event bracketing (tomo_profile_enable) and launch-error check

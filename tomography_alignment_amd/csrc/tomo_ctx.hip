@@ -137,6 +137,16 @@ extern "C" int tomo_sync(tomo_ctx *ctx)
     return TOMO_OK;
 }
 
+// HIP's current device is a per-thread setting and a new thread starts on device 0: a caller that uses a context from a thread other
+// than the one that created it (alignment.py evaluates its batches from a helper thread) binds the thread first.  Every entry point
+// that needs a geometry does the same on its own (TOMO_NEED_GEOM), this covers the rest (allocation, copies, collectives).
+extern "C" int tomo_ctx_make_current(tomo_ctx *ctx)
+{
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
+    TOMO_HIP(ctx, hipSetDevice(ctx->device));
+    return TOMO_OK;
+}
+
 extern "C" int tomo_set_option(tomo_ctx *ctx, const char *key, int value)
 {
     if (!ctx || !key) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
