@@ -822,5 +822,5 @@ def test_context_used_from_a_helper_thread(PM, orc, shepp32):
     t = threading.Thread(target=work)
     t.start()
     t.join()
-    assert np.array_equal(got["fwd"], want)
+    assert rel_max(got["fwd"], want) < 1e-6                                          # (float atomics: equal up to the order of the additions)
     assert np.all(got["cg"][0] < 1e-6 * np.sum(want.astype(np.float64) ** 2))       # cost of the exact projections ~ 0
