@@ -516,3 +516,21 @@ def test_reference_callers_run_unchanged_on_this_operator():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ref_callers_unchanged.py")], capture_output=True, text=True, timeout=600)
     print(r.stdout[-1500:])
     assert r.returncode == 0 and "run unchanged on this package's operator" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_f2py_twin_module_validates_and_fails_loudly_without_a_gpu():
+    """`src.ray_wt_grad` (the f2py module's name and signatures, INTEGRATION.md level 2 1/2): argument validation happens on the host, and
+    without a GPU the first real call raises TomoError -- there is no CPU fallback behind this surface either."""
+    from tomography_alignment_amd.src import ray_wt_grad
+    fp = np.zeros((3, 4, 5), np.int32)
+    wf = np.zeros((3, 4, 5))
+    with pytest.raises(ValueError):
+        ray_wt_grad.trilinear_ray_sparse(fp, wf[:, :3], 8, 8, 8, 4, 5)
+    with pytest.raises(ValueError):
+        ray_wt_grad.trilinear_ray_interp(fp, wf, 8, 8, 8, 4, 5, np.zeros(512), np.zeros((4, 4)), np.zeros((9, 3, 4)))
+    with pytest.raises(ValueError):
+        ray_wt_grad.trilinear_ray_interp(fp, wf, 8, 8, 8, 4, 5, np.zeros(100), np.zeros((4, 5)), np.zeros((9, 3, 4)))
+    n = ctypes.c_int(0)
+    if _lib.load().tomo_device_count(ctypes.byref(n)) != 0 or n.value == 0:
+        with pytest.raises(_lib.TomoError):
+            ray_wt_grad.trilinear_ray_sparse(fp, wf, 8, 8, 8, 4, 5)
