@@ -58,6 +58,9 @@ def main(out_path):
                                                                           "ground_truth": g["gt"] if "gt" in g else rec})
     rec_p, err_p = sp.run_main_iteration(niter=4)
     assert sg._pipelined and not sp._pipelined
+    # Tikhonov gradient descent (recon/sirt_mpi.py:148-: the data terms of f, f' and the gradient summed over the ranks)
+    rr = sirt_mpi.SIRT(comm, geo, g["b"].copy(), angles, g["xyz"], options={"_backend": OracleBackend(shard)})
+    rec_r, err_r = rr.run_regularized_gradient_descent(niter=3, reg_param=0.5, positivity=True)
     c = cgls_mpi.CGLS(comm, geo, g["b"].copy(), angles, g["xyz"], options={"_backend": OracleBackend(shard)})
     crec, cerr = c.run_main_iteration(niter=4)
     # sharded alignment: projections split over the ranks, replicated volume, one table all-reduce at the end
@@ -78,7 +81,7 @@ def main(out_path):
                  n_slab_sirt=n_slab_sirt, pipelined=pipelined, n_rs=n_rs, n_ag=n_ag, n_wg=n_wg, slab_sizes=slab_sizes, rec_a=rec_a, err_a=err_a,
                  n_slab_allreduce_form=n_slab_allreduce_form, n_fwd_whole=n_fwd_whole, rec_d=rec_d, err_d=err_d,
                  declined_pipelined=declined["pipelined"], declined_n_vol=declined["n_vol"], declined_n_slab=declined["n_slab"],
-                 rec_g=rec_g, err_g=err_g, rec_p=rec_p, err_p=err_p,
+                 rec_g=rec_g, err_g=err_g, rec_p=rec_p, err_p=err_p, rec_r=rec_r, err_r=err_r,
                  align_x=ares["x"], align_fun=ares["fun"], align_true=true, align_nfev=ares["nfev"])
     dist.barrier()
     dist.destroy_process_group()

@@ -132,6 +132,10 @@ class OracleBackend(object):
     def update_acc_fetch(self):
         return self._acc
 
+    def triplets(self, pose):
+        p = pose[0]
+        return orc.forward_sparse(self.og, p[1], p[2], p[0], p[3:6], np.array([p[6], 0., 0.]))
+
     def proj_grad(self, pose, vol, proj_out, grad_out, row_order=0):
         self.calls["proj_grad"] += 1
         p, g = orc.projection_gradient(self.og, vol.a, pose[0, 1], pose[0, 2], pose[0, 0], pose[0, 3:6], np.array([pose[0, 6], 0, 0]))

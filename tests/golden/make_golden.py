@@ -446,7 +446,29 @@ def g11():
     save("g11_cgls", **out)
 
 
+# ------------------------------------------------------------------ G12 SIRT.run_regularized_gradient_descent
+def g12():
+    """recon/sirt.py:109-197: Tikhonov gradient descent with scipy's strong-Wolfe line search on my_f / my_fp, the reference's class on its own CSR.
+    G5's sinogram (32^3, 16 angles); a: reg_param 0.5, positivity on, 6 iterations; b: reg_param 5.0, positivity off, ground truth, 5 iterations."""
+    g5 = np.load(os.path.join(HERE, "g5_sirt.npz"))
+    N, n_proj = 32, 16
+    geo = geom(n_proj, N)
+    angles = np.array([g5["phi"], g5["alpha"], g5["beta"]]).T
+    x = generate_phantom.shepp3d(N)
+    out = {}
+    for tag, reg, pos, gt, nit in (("a", 0.5, True, None, 6), ("b", 5.0, False, x, 5)):
+        opts = {} if gt is None else {"ground_truth": gt.copy()}
+        s = sirt.SIRT(geo, g5["b"].copy(), angles, g5["xyz"], options=opts)
+        rec, err = s.run_regularized_gradient_descent(niter=nit, reg_param=reg, positivity=pos)
+        out["rec_" + tag] = np.array(rec, np.float32)
+        out["err_" + tag] = np.array(err)
+        out["reg_" + tag], out["pos_" + tag], out["nit_" + tag] = np.array(reg), np.array(int(pos)), np.array(nit)
+    xs = np.random.default_rng(12).standard_normal(N ** 3).astype(np.float32)
+    out.update(f_x=xs, my_f=np.array(sirt.my_f(xs, s.proj_mat, g5["b"], 0.7)), my_fp=np.asarray(sirt.my_fp(xs, s.proj_mat, g5["b"], 0.7)))
+    save("g12_sirt_regularized_gd", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g7", "g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g7", "g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10", "g11", "g12"]
     for w in which:
         globals()[w]()

@@ -69,6 +69,8 @@ def test_sharded_solvers_match_unsharded(tmp_path):
     for w in (one, two):
         assert rel_max(w["rec_g"], w["rec_p"]) < 1e-5 and np.allclose(w["err_g"], w["err_p"], rtol=1e-5)
     assert rel_max(two["rec_g"], one["rec_g"]) < 1e-5
+    # Tikhonov gradient descent with scipy's line search: the data terms summed over the ranks == unsharded
+    assert rel_max(two["rec_r"], one["rec_r"]) < 1e-5 and np.allclose(two["err_r"], one["err_r"], rtol=1e-5)
     # sharded alignment: every rank aligns its block, the gathered table is the unsharded answer and recovers the poses
     assert np.allclose(two["align_x"], one["align_x"], atol=1e-9) and np.array_equal(two["align_nfev"], one["align_nfev"])
     assert np.allclose(two["align_x"], two["align_true"], atol=2e-4) and np.all(two["align_fun"] < 1e-6)

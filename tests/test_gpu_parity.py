@@ -824,3 +824,34 @@ def test_context_used_from_a_helper_thread(PM, orc, shepp32):
     t.join()
     assert rel_max(got["fwd"], want) < 1e-6                                          # (float atomics: equal up to the order of the additions)
     assert np.all(got["cg"][0] < 1e-6 * np.sum(want.astype(np.float64) ** 2))       # cost of the exact projections ~ 0
+
+
+def test_ray_voxel_utilities_mirror_gpu(shepp32):
+    """utilities/ray_voxel_utilities.py::forward_sparse / forward_proj_grad (the reference's names and returns, :53-170) on the library:
+    G1 b's assembled CSR from the per-projection triplets, G3's projection + 6-row gradient, geometry not shifted in place."""
+    import copy
+    from scipy import sparse
+    from tomography_alignment_amd.utilities import ray_voxel_utilities as rvu
+    from tomography_alignment_amd.utilities.geometry import Geometry
+    g1 = golden("g1_operator")
+    N, n_proj = 8, len(g1["b_phi"])
+    rows, cols, vals = [], [], []
+    for ip in range(n_proj):
+        geo = Geometry(1, np.array([N] * 3), np.ones(3), np.array([N, N]), np.ones(2))
+        geo.cor_shift = g1["b_cor"][ip]
+        before = copy.deepcopy(geo.source_centers)
+        dat, det, wts = rvu.forward_sparse(geo, g1["b_alpha"][ip], g1["b_beta"][ip], g1["b_phi"][ip], g1["b_xyz"][ip])
+        assert np.array_equal(geo.source_centers, before)
+        rows.append(det.astype(np.int64) + ip * N * N)
+        cols.append(dat.astype(np.int64))
+        vals.append(wts)
+    A = sparse.csr_matrix(sparse.coo_matrix((np.concatenate(vals).astype(np.float32), (np.concatenate(rows), np.concatenate(cols))), shape=tuple(g1["b_shape"])))
+    A.sum_duplicates()
+    A.sort_indices()
+    assert np.array_equal(A.indptr, g1["b_indptr"]) and np.array_equal(A.indices, g1["b_indices"]) and rel_max(A.data, g1["b_data"]) < 1e-6
+    g3 = golden("g3_proj_grad")
+    for i in range(3):
+        geo = Geometry(1, np.array([32] * 3), np.ones(3), np.array([32, 32]), np.ones(2))
+        geo.cor_shift = g3["cor"][i]
+        p, gr = rvu.forward_proj_grad(geo, g3["alpha"][i], g3["beta"][i], g3["phi"][i], g3["xyz"][i], shepp32)
+        assert p.dtype == np.float64 and gr.shape == (6, 1024) and rel_max(p, g3["proj"][i]) < TOL and rel_max(gr, g3["grad"][i]) < TOL

@@ -384,3 +384,22 @@ def test_volume_residency_is_explicit(shepp32):
     d.upload(2.0 * x)                                   # mutated in place behind the operator's back
     p7, _ = P.projection_gradient(d, **pose)
     assert rel_max(p6, p5) < 1e-7 and rel_max(p7, 2.0 * p5) < 1e-6
+
+
+def test_sirt_regularized_gradient_descent_vs_reference_golden_g12(shepp32, capsys):
+    """recon/sirt.py::SIRT.run_regularized_gradient_descent (reference :109-180: Tikhonov gradient descent, scipy strong-Wolfe line search on
+    my_f / my_fp) on the GPU operator against golden G12 -- the reference's class on its own CSR -- at 1e-5; my_f / my_fp themselves too."""
+    from tomography_alignment_amd.recon import sirt as sirt_mod
+    g5, g = golden("g5_sirt"), golden("g12_sirt_regularized_gd")
+    geo = geom(16, 32)
+    angles = np.array([g5["phi"], g5["alpha"], g5["beta"]]).T
+    for tag, gt in (("a", None), ("b", shepp32)):
+        opts = {} if gt is None else {"ground_truth": gt.copy()}
+        s = sirt_mod.SIRT(geo, g5["b"].copy(), angles, g5["xyz"], options=opts)
+        rec, err = s.run_regularized_gradient_descent(niter=int(g["nit_" + tag]), reg_param=float(g["reg_" + tag]), positivity=bool(g["pos_" + tag]))
+        e, er = rel_max(rec, g["rec_" + tag]), float(np.max(np.abs(err - g["err_" + tag]) / g["err_" + tag]))
+        with capsys.disabled():
+            print("Tikhonov gradient descent vs the reference's class (G12 %s): rec rel-max %.2e, rms rel %.2e" % (tag, e, er))
+        assert len(err) == len(g["err_" + tag]) and e < 1e-5 and er < 1e-5
+    assert abs(sirt_mod.my_f(g["f_x"], s.proj_mat, g5["b"], 0.7) / float(g["my_f"]) - 1) < 1e-6
+    assert rel_max(sirt_mod.my_fp(g["f_x"], s.proj_mat, g5["b"], 0.7), g["my_fp"]) < 1e-5

@@ -534,3 +534,68 @@ def test_f2py_twin_module_validates_and_fails_loudly_without_a_gpu():
     if _lib.load().tomo_device_count(ctypes.byref(n)) != 0 or n.value == 0:
         with pytest.raises(_lib.TomoError):
             ray_wt_grad.trilinear_ray_sparse(fp, wf, 8, 8, 8, 4, 5)
+
+
+def test_ray_voxel_utilities_mirror(shepp32):
+    """utilities/ray_voxel_utilities.py under the reference's function names (round 4): the two numpy helpers against the oracle's
+    restatement, `forward_sparse` / `forward_proj_grad` (CPU stand-in backend here; the GPU twin is tests/test_gpu_parity.py) against the
+    reference's goldens G1 b (assembled CSR) and G3 (projection_gradient), and the geometry is NOT shifted in place."""
+    import copy
+    from oracle import oracle as orc
+    from tomography_alignment_amd.utilities import ray_voxel_utilities as rvu
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((3, 7))
+    t = rng.standard_normal(3)
+    assert np.allclose(rvu.transform_points(x, 0.01, -0.02, 1.1, t), orc.transform_points(x, 0.01, -0.02, 1.1, t), rtol=0, atol=1e-15)
+    assert np.allclose(rvu.derivative_ray_points(x, np.array([0., 16., 0.]), 0.01, -0.02, 1.1, t),
+                       orc.derivative_ray_points(x, np.array([0., 16., 0.]), 0.01, -0.02, 1.1, t), rtol=0, atol=1e-13)
+    g1 = golden("g1_operator")
+    N, n_proj = 8, len(g1["b_phi"])
+    rows, cols, vals = [], [], []
+    for ip in range(n_proj):
+        geo = geom(1, N)
+        geo.cor_shift = g1["b_cor"][ip]                      # as utilities/projection_operators.py:101-102 hands it over
+        before = copy.deepcopy(geo.source_centers)
+        dat, det, wts = rvu.forward_sparse(geo, g1["b_alpha"][ip], g1["b_beta"][ip], g1["b_phi"][ip], g1["b_xyz"][ip], backend=OracleBackend(geo))
+        assert np.array_equal(geo.source_centers, before) and dat.dtype == np.int32 and wts.dtype == np.float64
+        rows.append(det.astype(np.int64) + ip * N * N)
+        cols.append(dat.astype(np.int64))
+        vals.append(wts)
+    A = sparse.csr_matrix(sparse.coo_matrix((np.concatenate(vals).astype(np.float32), (np.concatenate(rows), np.concatenate(cols))), shape=tuple(g1["b_shape"])))
+    A.sum_duplicates()
+    A.sort_indices()
+    assert np.array_equal(A.indptr, g1["b_indptr"]) and np.array_equal(A.indices, g1["b_indices"]) and rel_max(A.data, g1["b_data"]) < 1e-6
+    # ProjectionMatrix._forward_ray (reference utilities/projection_operators.py:95-110): the lists its projection_matrix concatenates
+    geo = Geometry(n_proj, np.array([N] * 3), np.ones(3), np.array([N, N]), np.ones(2), cor_shift=g1["b_cor"])
+    P = projection_operators.ProjectionMatrix(geo, backend=OracleBackend(geo))
+    P.projection_matrix(alpha=g1["b_alpha"], beta=g1["b_beta"], phi=g1["b_phi"], xyz_shift=g1["b_xyz"])
+    w, di, da = P._forward_ray()
+    A2 = sparse.csr_matrix(sparse.coo_matrix((np.concatenate(w), (np.concatenate(di), np.concatenate(da))), shape=tuple(g1["b_shape"])))
+    A2.sum_duplicates()
+    A2.sort_indices()
+    assert w[0].dtype == np.float32 and np.array_equal(A2.indices, g1["b_indices"]) and rel_max(A2.data, g1["b_data"]) < 1e-6
+    g3 = golden("g3_proj_grad")
+    for i in range(3):
+        geo = geom(1, 32)
+        geo.cor_shift = g3["cor"][i]
+        p, gr = rvu.forward_proj_grad(geo, g3["alpha"][i], g3["beta"][i], g3["phi"][i], g3["xyz"][i], shepp32, backend=OracleBackend(geo))
+        assert p.dtype == np.float64 and gr.shape == (6, 1024) and rel_max(p, g3["proj"][i]) < 1e-5 and rel_max(gr, g3["grad"][i]) < 1e-5
+
+
+def test_sirt_regularized_gradient_descent_vs_reference_golden_g12(shepp32):
+    """recon/sirt.py::SIRT.run_regularized_gradient_descent + my_f / my_fp (reference :109-197; round 4) on the CPU stand-in backend against
+    golden G12 (the reference's class on its own CSR): scipy's strong-Wolfe line search runs on this package's operator."""
+    from tomography_alignment_amd.recon import sirt as sirt_mod
+    g5, g = golden("g5_sirt"), golden("g12_sirt_regularized_gd")
+    geo = geom(16, 32)
+    angles = np.array([g5["phi"], g5["alpha"], g5["beta"]]).T
+    for tag, gt in (("a", None), ("b", shepp32)):
+        opts = {"_backend": OracleBackend(geo)}
+        if gt is not None:
+            opts["ground_truth"] = gt.copy()
+        s = sirt.SIRT(geo, g5["b"].copy(), angles, g5["xyz"], options=opts)
+        rec, err = s.run_regularized_gradient_descent(niter=int(g["nit_" + tag]), reg_param=float(g["reg_" + tag]), positivity=bool(g["pos_" + tag]))
+        assert rec.shape == (32, 32, 32) and len(err) == len(g["err_" + tag])
+        assert rel_max(rec, g["rec_" + tag]) < 2e-5 and np.allclose(err, g["err_" + tag], rtol=2e-5)
+    assert abs(sirt_mod.my_f(g["f_x"], s.proj_mat, g5["b"], 0.7) / float(g["my_f"]) - 1) < 1e-6
+    assert rel_max(sirt_mod.my_fp(g["f_x"], s.proj_mat, g5["b"], 0.7), g["my_fp"]) < 1e-5

@@ -54,6 +54,10 @@ class SIRT(object):
     def _allreduce_scalar(self, v):
         return v
 
+    def _allreduce_host(self, a):
+        """Sum of a HOST array over the ranks (identity here)."""
+        return a
+
     def _is_root(self):
         return True
 
@@ -164,9 +168,77 @@ class SIRT(object):
         self.proj_mat.T.apply(self.d_res, self.d_bp)                                    # sirt.py:61
         self._allreduce_vol(self.d_bp)                                                  # sirt_mpi.py:102-103
 
+    def run_regularized_gradient_descent(self, niter=100, reg_param=1.0, positivity=True, make_plot=False, debug=False):
+        """Tikhonov-regularised least squares by gradient descent, step by scipy's strong-Wolfe `optimize.line_search` on
+        `my_f` / `my_fp` below -- the reference's recon/sirt.py:109-180, same defaults, same stop rule (k > 1 and rms rising),
+        same fallback step 1e-3 when the line search gives up.  A secondary method: the iterate lives on the HOST (scipy's line
+        search does its own arithmetic on numpy arrays), every function / gradient evaluation is one forward (+ one
+        back-projection) through the operator with the volume crossing PCIe -- fine at the sizes it is used at; the
+        device-resident solver is run_main_iteration / iterate_device."""
+        from scipy import optimize
+        if make_plot:
+            print('make_plot is not supported on the device-resident solver; ignoring')
+        A = self.proj_mat
+        n_rows = np.size(self._rows)
+        if self.be.is_buffer(self.projections):
+            b = np.asarray(self.be.download(self.projections), np.float32).reshape(n_rows, -1)      # this rank's rows, already in HBM
+        else:
+            b = np.asarray(self.projections, np.float32).reshape(self.n_proj, -1)[self._rows]
+        # angle-sharded subclass: A and b are this rank's rows; the data terms are summed over the ranks (recon/sirt_mpi.py:160-178)
+        host_sum, scalar_sum = self._allreduce_host, self._allreduce_scalar
+
+        def f(x, A_, b_, lam):
+            r_ = A_.dot(np.ravel(x)) - np.ravel(b_)
+            return scalar_sum(0.5 * float(np.linalg.norm(r_)) ** 2) + 0.5 * lam * np.linalg.norm(x) ** 2
+
+        def fp(x, A_, b_, lam):
+            r_ = A_.dot(np.ravel(x)) - np.ravel(b_)
+            return host_sum(A_.T.dot(r_)) + lam * x
+        sharded = type(self)._allreduce_host is not SIRT._allreduce_host       # unsharded: the module-level my_f / my_fp, as the reference
+        rec = np.array(self.be.download(self.d_rec), np.float32)                      # sirt.py:19 (the current reconstruction)
+        if self.ground_truth is not None:
+            gt = np.asarray(self.ground_truth if not self.be.is_buffer(self.ground_truth) else self.be.download(self.ground_truth)).ravel()
+            norm_factor = np.linalg.norm(gt)                                           # :115-117
+        else:
+            gt, norm_factor = None, np.sqrt(self._allreduce_scalar(float(np.linalg.norm(b)) ** 2))      # :119
+        stop, k = 0, 0
+        rms_error, convergence = np.zeros((niter,)), np.zeros((niter,))
+        while k < niter and not stop:
+            res = b - A.dot(rec).reshape(n_rows, -1)                                   # :128-129
+            grad = -host_sum(A.T.dot(res.ravel())) + reg_param * rec                   # :130,132   A^T(A x - b) + lambda x
+            alpha = optimize.line_search(f if sharded else my_f, fp if sharded else my_fp, rec, -grad, args=(A, b, reg_param))[0]      # :135-137
+            if alpha is None:
+                alpha = 1.e-3                                                          # :138-139
+            rec -= alpha * grad                                                        # :142
+            if positivity:
+                rec[rec < 0.] = 0.                                                     # :145-146
+            convergence[k] = np.sqrt(self._allreduce_scalar(float(np.linalg.norm(res)) ** 2))
+            rms_error[k] = convergence[k] / norm_factor if gt is None else np.linalg.norm(gt - rec) / norm_factor      # :148-152
+            if k > 1 and rms_error[k] > rms_error[k - 1]:                              # :154
+                stop = 1
+                if self._is_root():
+                    print('semi-convergence criterion reached: stopping at k %3d with RMSE = %4.5f' % (k, rms_error[k]))
+            k += 1
+        self.rec = rec
+        self.d_rec.upload(rec)
+        self.rms_error, self.convergence = rms_error, convergence
+        return rec.reshape(tuple(int(v) for v in self.geometry.vox_shape)), rms_error[:k]
+
     def run_main_iteration(self, niter=100, make_plot=False, projections=None, positivity=False, debug=False):
         if make_plot:
             print('make_plot is not supported on the device-resident solver; ignoring')
         k, rms = self.iterate_device(niter=niter, positivity=positivity, projections=projections, debug=debug)
         self.rec = self.be.download(self.d_rec)
         return self.rec.reshape(tuple(int(v) for v in self.geometry.vox_shape)), rms
+
+
+def my_f(x, A, b, _lambda):
+    """0.5 |A x - b|^2 + 0.5 lambda |x|^2      (recon/sirt.py:183-189); A: any operator with .dot (a RayOperator, a scipy matrix)."""
+    res = A.dot(np.ravel(x)) - np.ravel(b)
+    return 0.5 * np.linalg.norm(res) ** 2 + 0.5 * _lambda * np.linalg.norm(x) ** 2
+
+
+def my_fp(x, A, b, _lambda):
+    """A^T (A x - b) + lambda x      (recon/sirt.py:192-197)."""
+    res = A.dot(np.ravel(x)) - np.ravel(b)
+    return A.T.dot(res) + _lambda * x

@@ -57,6 +57,14 @@ class SIRT(_SIRT):
     def _allreduce_scalar(self, v):
         return self.comm.allreduce_scalar(v)
 
+    def _allreduce_host(self, a):
+        """Sum of a host array over the ranks (run_regularized_gradient_descent: recon/sirt_mpi.py:160-178)."""
+        if self.size == 1:
+            return a
+        out = np.array(a, np.float64)
+        self.comm.allreduce_array(out)
+        return out.astype(np.asarray(a).dtype, copy=False)
+
     def _is_root(self):
         return self.my_rank == 0
 

@@ -229,6 +229,23 @@ class ProjectionMatrix(object):
             data_inds.append(dat)
         return weights, detector_inds, data_inds
 
+    def _forward_ray(self):
+        """Per-projection triplets of the ray-driven projector (reference utilities/projection_operators.py:95-110: what its
+        projection_matrix concatenates into the COO matrix); small volumes only.  Needs projection_matrix() to have set
+        angles / xyz_shift first.  `RayOperator.tocsr()` is the assembled form."""
+        import copy
+        from . import ray_voxel_utilities
+        weights, detector_inds, data_inds = [], [], []
+        for iproj in range(self.n_proj):
+            this_geo = copy.copy(self.geometry)
+            this_geo.cor_shift = np.asarray(self.geometry.cor_shift)[iproj]
+            phi, alpha, beta = self.angles[iproj]
+            dat, det, wts = ray_voxel_utilities.forward_sparse(this_geo, alpha, beta, phi, self.xyz_shift[iproj], backend=self.backend)
+            weights.append(wts.astype(self.precision, copy=False))
+            data_inds.append(dat.astype(np.int32))
+            detector_inds.append(det + iproj * int(self.geometry.n_det))
+        return weights, detector_inds, data_inds
+
     # ---- volume residency for repeated projection_gradient calls (alignment inner loop)
     # The reference recomputes from `rec` on every call (utilities/projection_operators.py:112-122), so by default so does
     # this class: a host `rec` is uploaded and re-staged on EVERY call, a DeviceArray is re-staged on every call.  Keeping a
