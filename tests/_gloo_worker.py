@@ -40,6 +40,16 @@ def main(out_path):
     sa.shard_update = False
     rec_a, err_a = sa.run_main_iteration(niter=6, positivity=True)
     n_slab_allreduce_form = comm.n_slab_allreduce - s0_
+    # ... with a ground truth too: EVERY rank must see the same error curve (the stop rule hangs on it: a rank that stopped alone would
+    # leave its peers in a collective), whichever form sums the slabs
+    curves = []
+    for shard_update in (True, False):
+        sgt = sirt_mpi.SIRT(comm, geo, g["b"].copy(), angles, g["xyz"], options={"_backend": OracleBackend(shard), "ground_truth": rec})
+        sgt.shard_update = shard_update
+        _, e_gt = sgt.run_main_iteration(niter=3, positivity=True)
+        curves.append((e_gt, comm.allreduce_max(float(e_gt[-1])) - (-comm.allreduce_max(-float(e_gt[-1])))))
+    err_gt_sharded, err_gt_allreduce = curves[0][0], curves[1][0]
+    rank_spread = max(curves[0][1], curves[1][1])          # largest difference between the ranks' last rms value (0 when they agree)
     # the same run with a stand-in backend that DECLINES the tile kernels on the last rank only (an angle block holding a pose
     # tilted beyond their domain): the decision is collective, so every rank must take the plain sequence -- one whole-volume
     # all-reduce per iteration on every rank, no slab all-reduce anywhere -- and the result must not change
@@ -79,7 +89,7 @@ def main(out_path):
     if comm.rank == 0:
         np.savez(out_path, rec=rec, err=err, crec=crec, cerr=cerr, n_allreduce_sirt=n_allreduce_sirt, cor=cor,
                  n_slab_sirt=n_slab_sirt, pipelined=pipelined, n_rs=n_rs, n_ag=n_ag, n_wg=n_wg, slab_sizes=slab_sizes, rec_a=rec_a, err_a=err_a,
-                 n_slab_allreduce_form=n_slab_allreduce_form, n_fwd_whole=n_fwd_whole, rec_d=rec_d, err_d=err_d,
+                 n_slab_allreduce_form=n_slab_allreduce_form, err_gt_sharded=err_gt_sharded, err_gt_allreduce=err_gt_allreduce, rank_spread=rank_spread, n_fwd_whole=n_fwd_whole, rec_d=rec_d, err_d=err_d,
                  declined_pipelined=declined["pipelined"], declined_n_vol=declined["n_vol"], declined_n_slab=declined["n_slab"],
                  rec_g=rec_g, err_g=err_g, rec_p=rec_p, err_p=err_p, rec_r=rec_r, err_r=err_r,
                  align_x=ares["x"], align_fun=ares["fun"], align_true=true, align_nfev=ares["nfev"])

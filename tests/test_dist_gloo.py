@@ -55,12 +55,17 @@ def test_sharded_solvers_match_unsharded(tmp_path):
     assert int(one["n_allreduce_sirt"]) == 1 + len(one["err"]) and int(one["n_slab_sirt"]) == 0 and int(one["n_rs"]) == 0
     # the all-reduce form of the pipeline (shard_update = False: round 3) gives the same reconstruction with 3 slab all-reduces per iteration
     assert int(two["n_slab_allreduce_form"]) == 3 * n_it and rel_max(two["rec_a"], two["rec"]) < 1e-5 and np.allclose(two["err_a"], two["err"], rtol=1e-5)
+    # with a ground truth the error curve is the same on EVERY rank in both forms (a rank that saw another curve could stop alone and leave
+    # its peers in a collective) and equals the unsharded one
+    for w in (one, two):
+        assert float(w["rank_spread"]) < 1e-12 and np.allclose(w["err_gt_sharded"], one["err_gt_sharded"], rtol=1e-5) and np.allclose(w["err_gt_allreduce"], one["err_gt_sharded"], rtol=1e-5)
     # world 3: slabs that do not split evenly -- pieces by reduce-scatter, the < 3 left-over voxels of a slab by a small all-reduce
     three = _run(3, str(tmp_path / "w3.npz"))
     assert bool(three["pipelined"]) and int(three["n_rs"]) == 3 * n_it and 0 < int(three["n_slab_sirt"]) <= 3 * n_it
     assert int(three["slab_sizes"].sum()) == 32 ** 3 and int(three["slab_sizes"].min()) < 3
     assert rel_max(three["rec"], one["rec"]) < 1e-5 and np.allclose(three["err"], one["err"], rtol=1e-5)
     assert rel_max(three["rec_g"], one["rec_g"]) < 1e-5 and np.allclose(three["err_g"], one["err_g"], rtol=1e-5)     # error sums over pieces + tails
+    assert float(three["rank_spread"]) < 1e-12 and np.allclose(three["err_gt_sharded"], one["err_gt_sharded"], rtol=1e-5)
     # a rank whose block declines the tile kernels: EVERY rank takes the plain sequence (rank-uniform collectives), same result
     assert not bool(two["declined_pipelined"]) and int(two["declined_n_slab"]) == 0 and int(two["declined_n_vol"]) == 1 + n_it
     assert rel_max(two["rec_d"], two["rec"]) < 1e-5 and np.allclose(two["err_d"], two["err"], rtol=1e-5)

@@ -173,6 +173,9 @@ class SIRT(_SIRT):
         if ahead:
             self.d_ax.zero_()                       # stream order: after the residual kernel has read it
         first, gathers, fwd_after = True, 0, None
+        # with pieces, a rank sums (gt - rec)^2 over its own voxels, rank 0 adds the tails, and one scalar all-reduce completes it; in the
+        # all-reduce form (no pieces anywhere) every rank updates -- and sums over -- everything, as in round 3, and nothing is reduced
+        any_piece = any(self._pieces((x_hi - x_lo) * plane)[0] for _, (x_lo, x_hi), _ in self._plan)
 
         def upd(o, n, with_gt):
             nonlocal first
@@ -193,7 +196,7 @@ class SIRT(_SIRT):
                 upd(o + r * piece, piece, True)                     # 1/P of the slab: V scaling, positivity, error sum
             if tail:
                 comm.wait_next()                                    # the tail's all-reduce
-                upd(o + piece * P, tail, r == 0)                    # identical on every rank; its error counted once
+                upd(o + piece * P, tail, r == 0 or not any_piece)   # identical on every rank; its error counted once
             if piece:
                 comm.allgather_async(self.d_rec.view(o, piece * P), piece)      # after the update (stream order -> communication stream)
                 gathers += 1
@@ -215,7 +218,7 @@ class SIRT(_SIRT):
         err = be.update_acc_fetch()
         # with pieces every rank summed (gt - rec)^2 over its own voxels only (and rank 0 over the tails): one more scalar all-reduce,
         # issued by every rank alike (whether a ground truth is given is a property of the run, not of a rank)
-        return self._allreduce_scalar(err) if any(self._pieces((x_hi - x_lo) * plane)[0] for _, (x_lo, x_hi), _ in self._plan) else err
+        return self._allreduce_scalar(err) if any_piece else err
 
     def iterate_device(self, niter=100, positivity=False, projections=None, debug=False):
         self._ax_ready = False                      # a projection made ahead never outlives the call that made it
