@@ -253,6 +253,17 @@ TOMO_API int tomo_tv_norm_3d(tomo_ctx *ctx, const float *d_x, int nx, int ny, in
  * tomo_release_workspace frees it (synchronises the stream first).  The next call that needs it allocates it again. */
 TOMO_API int tomo_release_workspace(tomo_ctx *ctx);
 
+/* ---------------------------------------------------------------- the assembled CSR matrix, built on the device (csrc/tomo_csr.hip)
+ * Replaces utilities/projection_operators.py:54-76: per-projection triplets of src/ray_wt_grad.f90:1-92 (float64 weights cast to
+ * `precision`, row = detector index + iproj * n_det), optional voxel mask (d_mask: device float[n_vox], 0 = masked out; NULL = none;
+ * when EVERY entry is masked the reference keeps them all with weight 0, :63-65 -- so does this), COO -> CSR with duplicates summed,
+ * explicit zeros kept, column indices sorted.  tomo_csr_assemble builds the matrix in device memory held by the context and returns its
+ * number of stored entries; tomo_csr_fetch copies data (float32 or float64 by precision_bits) / indices (int32) / indptr (int64,
+ * n_proj * n_det + 1) into the caller's host arrays and frees the device copy.  Small volumes only (the reference's matrix at
+ * 128^3 x 64 is 4.5 GB); TOMO_ERR_UNSUPPORTED beyond int32 indices or 2^31 triplets. */
+TOMO_API int tomo_csr_assemble(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_mask, int precision_bits, int64_t *h_nnz);
+TOMO_API int tomo_csr_fetch(tomo_ctx *ctx, void *h_data, int32_t *h_indices, int64_t *h_indptr);
+
 /* ---------------------------------------------------------------- array-level twins of the two f2py routines (csrc/tomo_f2py.hip)
  * For a binding one level BELOW the operator API: utilities/ray_voxel_utilities.py:103,164 call
  *   dat_inds, det_inds, wts, n_inds = ray_wt_grad.trilinear_ray_sparse(floor_points, w_floor, nx, ny, nz, n_rays, n_points)   src/ray_wt_grad.f90:1-92

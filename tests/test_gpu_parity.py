@@ -855,3 +855,41 @@ def test_ray_voxel_utilities_mirror_gpu(shepp32):
         geo.cor_shift = g3["cor"][i]
         p, gr = rvu.forward_proj_grad(geo, g3["alpha"][i], g3["beta"][i], g3["phi"][i], g3["xyz"][i], shepp32)
         assert p.dtype == np.float64 and gr.shape == (6, 1024) and rel_max(p, g3["proj"][i]) < TOL and rel_max(gr, g3["grad"][i]) < TOL
+
+
+def test_csr_assembled_on_the_device_equals_host_assembly(PM, capsys):
+    """SURVEY 8f row N3 in full (round 4): RayOperator.tocsr() builds the reference's CSR (utilities/projection_operators.py:54-76) ON THE
+    DEVICE -- triplets of all projections, mask filter, radix sort, duplicate sums, row pointers (csrc/tomo_csr.hip) -- against round 3's
+    form (device triplets, scipy sort + merge on the host): same structure bit for bit, data to one float32 / float64 rounding of a duplicate
+    sum; ragged shape, tilted poses, a voxel mask, both precisions, the all-masked case (the reference keeps every entry with weight 0,
+    :63-65), the transposed operator; and what it buys at 64^3 x 8 (printed)."""
+    import time
+    from scipy import sparse
+    rng = np.random.default_rng(77)
+    shape, ndet, n = (24, 20, 28), (26, 30), 5
+    geo, _ = geo_pair(n, None, ndet=ndet, shape=shape)
+    phi = rng.uniform(0, np.pi, n)
+    alpha, beta = np.deg2rad(rng.uniform(-2, 2, n)), np.deg2rad(rng.uniform(-2, 2, n))
+    xyz = rng.uniform(-2, 2, (n, 3))
+    mask = rng.uniform(size=shape) > 0.4
+    for prec, tol in ((np.float32, 3e-7), (np.float64, 1e-15)):
+        for m in (None, mask, np.zeros(shape, bool)):
+            A = PM(geo, precision=prec).projection_matrix(alpha=alpha, beta=beta, phi=phi, xyz_shift=xyz, voxel_mask=m)
+            D, H = A.tocsr(), A.tocsr(device=False)
+            H.sum_duplicates()
+            H.sort_indices()
+            assert D.dtype == H.dtype == np.dtype(prec) and D.shape == H.shape and D.has_sorted_indices
+            assert np.array_equal(D.indptr, H.indptr) and np.array_equal(D.indices, H.indices), (prec, m is None)
+            assert np.max(np.abs(D.data - H.data), initial=0.0) <= tol * max(1.0, np.max(np.abs(H.data), initial=0.0))
+            if m is not None and not m.any():
+                assert D.nnz > 0 and not D.data.any()                      # every entry kept, all weights zero
+            T = A.T.tocsr()
+            assert T.shape == (D.shape[1], D.shape[0]) and abs(T.sum() - D.sum()) <= 1e-5 * abs(D.sum()) + 1e-12
+    # what it buys: 64^3 x 8 (the reference itself: 35 s for 90 angles at this size, BASELINE.md section 2)
+    geo64, _ = geo_pair(8, 64)
+    A = PM(geo64).projection_matrix()
+    t0 = time.perf_counter(); D = A.tocsr(); t1 = time.perf_counter(); H = A.tocsr(device=False); t2 = time.perf_counter()
+    with capsys.disabled():
+        print("\n[CSR 64^3 x 8] %d stored entries: assembled on the device in %.2f s (incl. download), device triplets + scipy on the host %.2f s"
+              % (D.nnz, t1 - t0, t2 - t1))
+    assert D.nnz == H.nnz

@@ -85,6 +85,8 @@ SIGNATURES = {
                                              ctypes.c_int, ctypes.POINTER(ctypes.c_int), _c_dp]),
     "tomo_tv_norm_3d": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp]),
     "tomo_release_workspace": (ctypes.c_int, [_c_vp]),
+    "tomo_csr_assemble": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]),
+    "tomo_csr_fetch": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp]),
     "tomo_trilinear_ray_interp": (ctypes.c_int, [_c_vp, _c_vp, _c_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
     "tomo_trilinear_ray_sparse": (ctypes.c_int, [_c_vp, _c_vp, _c_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp, _c_vp, _c_dp, _c_vp]),
     "tomo_comm_get_unique_id": (ctypes.c_int, [_c_vp]),

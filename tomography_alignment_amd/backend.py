@@ -140,6 +140,21 @@ class HipBackend(object):
                                                         _lib.dptr(cost), _lib.dptr(g6), resid.ptr if resid is not None else None))
         return cost, g6
 
+    def csr_assemble(self, poses, mask=None, precision=np.float32):
+        """The reference's assembled projection matrix (utilities/projection_operators.py:54-76) built on the device: triplets of all
+        projections, mask filter, sort, duplicate sums, row pointers -> (data [precision], indices int32, indptr int64)."""
+        self._geom()
+        bits = 64 if np.dtype(precision) == np.float64 else 32
+        nnz = ctypes.c_int64(0)
+        poses = np.ascontiguousarray(poses, np.float64)
+        self.ctx.check(self.lib.tomo_csr_assemble(self.ctx.handle, _lib.dptr(poses), poses.shape[0], mask.ptr if mask is not None else None, bits,
+                                                  ctypes.byref(nnz)))
+        data = np.empty(nnz.value, np.float64 if bits == 64 else np.float32)
+        indices = np.empty(nnz.value, np.int32)
+        indptr = np.empty(poses.shape[0] * self.n_det + 1, np.int64)
+        self.ctx.check(self.lib.tomo_csr_fetch(self.ctx.handle, data.ctypes.data_as(_c_vp), indices.ctypes.data_as(_c_vp), indptr.ctypes.data_as(_c_vp)))
+        return data, indices, indptr
+
     def triplets(self, pose):
         """COO triplets (dat_inds, det_inds, wts float64) of one projection in the emission order of
         src/ray_wt_grad.f90:1-92 (small volumes only)."""

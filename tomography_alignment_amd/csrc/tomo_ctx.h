@@ -66,6 +66,10 @@ struct tomo_ctx {
     // general float workspace (grow-only): the TV-FISTA proximal step keeps its 7 fields here across calls
     float *d_ws = nullptr;
     size_t ws_elems = 0;
+    // assembled CSR kept between tomo_csr_assemble and tomo_csr_fetch (tomo_csr.hip)
+    void *csr_data = nullptr, *csr_indices = nullptr, *csr_indptr = nullptr;
+    int64_t csr_nnz = 0, csr_rows = 0;
+    int csr_value_bytes = 4;
     // options
     int fwd_variant = 3;      // 1 ray-driven plain, 2 ray-driven SGPR-base, 3 LDS tile (default)
     int adj_variant = 2;      // 1 global float atomics, 2 LDS tile fixed-point (default)
@@ -100,6 +104,7 @@ int tomo_ensure_stage(tomo_ctx *ctx, size_t bytes);
 int tomo_ensure_red(tomo_ctx *ctx, size_t n_doubles);
 int tomo_ensure_ws(tomo_ctx *ctx, size_t n_floats);
 int tomo_ensure_blk(tomo_ctx *ctx, size_t n_ints);
+void tomo_csr_release(tomo_ctx *ctx);
 void tomo_prof_begin(tomo_ctx *ctx, const char *name);
 void tomo_prof_end(tomo_ctx *ctx);
 void tomo_prof_begin_on(tomo_ctx *ctx, const char *name, hipStream_t stream);

@@ -66,6 +66,7 @@ extern "C" int tomo_ctx_destroy(tomo_ctx *c)
     if (c->d_red) (void)hipFree(c->d_red);
     if (c->h_red) (void)hipHostFree(c->h_red);
     if (c->d_ws) (void)hipFree(c->d_ws);
+    tomo_csr_release(c);
     if (c->d_blk) (void)hipFree(c->d_blk);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

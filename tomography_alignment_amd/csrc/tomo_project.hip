@@ -626,6 +626,12 @@ extern "C" int tomo_cost_grad_rows(tomo_ctx *ctx, const double *h_poses, int n, 
     return TOMO_OK;
 }
 
+// the lattice constants of `n_proj` poses on the device, for tomo_csr.hip (valid until the next call that stages poses)
+int tomo_upload_projc_for_csr(tomo_ctx *ctx, const double *h_poses, int n_proj, ProjC **d_pc)
+{
+    return upload_projc(ctx, h_poses, n_proj, false, d_pc, nullptr);
+}
+
 // ------------------------------------------------------------------------------------------------
 // COO triplets of one projection (src/ray_wt_grad.f90:1-92 trilinear_ray_sparse): count -> scan -> fill, float64
 // weights, emission order ray-major / sample / corner (x slowest, z fastest, floor before ceil).  Small volumes only

@@ -143,14 +143,24 @@ class RayOperator(object):
         res = out.download()
         return res if self.dtype == np.float32 else res.astype(self.dtype)
 
-    def tocsr(self, max_nnz=2 ** 31 - 1):
+    def tocsr(self, max_nnz=2 ** 31 - 1, device=True):
         """Materialise the scipy CSR the reference's projection_matrix returns (utilities/projection_operators.py:56-76):
         per-projection COO triplets (emitted on the device with the order and float64 weights of
         src/ray_wt_grad.f90:1-92), weights cast to `precision`, optional voxel-mask filter, duplicates summed,
-        explicit zeros kept.  Meant for small volumes (N <= 128): 8 slots per sample."""
+        explicit zeros kept.  Meant for small volumes (N <= 128): 8 slots per sample.  `device=False`: round 3's form (triplets from
+        the device one projection at a time, scipy sorts and merges on the host) -- kept as the cross-check."""
         from scipy import sparse
         f, be = self._fwd, self.backend
         n_proj = f.poses.shape[0]
+        if device and hasattr(be, "csr_assemble") and np.dtype(f.precision) in (np.dtype(np.float32), np.dtype(np.float64)):
+            # round 4: everything on the device -- triplets of all projections, mask, sort, duplicate sums, row pointers (csrc/tomo_csr.hip);
+            # the host only receives the finished arrays
+            data, indices, indptr = be.csr_assemble(f.poses, f._mask, f.precision)
+            if data.size > max_nnz:
+                raise MemoryError("tocsr: more than %d entries; keep the operator matrix-free" % max_nnz)
+            idx = np.int32 if max(data.size, f.shape[1]) < 2 ** 31 - 1 else np.int64        # what scipy picks for a matrix of this size
+            A = sparse.csr_matrix((data, indices.astype(idx, copy=False), indptr.astype(idx, copy=False)), shape=f.shape)
+            return A.T.tocsr() if self._is_adjoint else A
         W, DET, DAT = [], [], []
         total = 0
         for ip in range(n_proj):
