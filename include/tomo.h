@@ -234,6 +234,17 @@ TOMO_API int tomo_vec_sub(tomo_ctx *ctx, float *d_out, const float *d_a, const f
 TOMO_API int tomo_vec_mul(tomo_ctx *ctx, float *d_y, const float *d_x, int64_t n);                     /* y *= x */
 TOMO_API int tomo_vec_dot(tomo_ctx *ctx, const float *d_a, const float *d_b, int64_t n, double *h_dot);
 TOMO_API int tomo_vec_diff_sumsq(tomo_ctx *ctx, const float *d_a, const float *d_b, int64_t n, double *h_sumsq);
+/* Several scalars of one solver iteration with ONE host synchronisation (round 5): TOMO_N_ACC double accumulators live on the device.
+ * tomo_acc_zero clears slots [slot0, slot0 + n); tomo_vec_dot_acc ADDS sum(a*b) (diff 0) or sum((a-b)^2) (diff 1) of a segment to a
+ * slot without touching the host -- so gamma = ||A^T r||^2 accumulates over the x slabs of a pipelined back-projection as their
+ * reductions arrive (recon/cgls_mpi.py:98-99), and ||A p||^2 and ||b - A p||^2 (:72-76) come from one pass over two slots;
+ * tomo_acc_fetch reads slots [slot0, slot0 + n) back -- with `allreduce` != 0 and a communicator, after ONE ncclAllReduce(sum) of
+ * exactly those slots on the compute stream: the three host-synchronous scalar allreduces of recon/cgls_mpi.py:75-76,107 become one
+ * small device-side collective per reduction point. */
+#define TOMO_N_ACC 16
+TOMO_API int tomo_acc_zero(tomo_ctx *ctx, int slot0, int n);
+TOMO_API int tomo_vec_dot_acc(tomo_ctx *ctx, const float *d_a, const float *d_b, int64_t n, int diff, int slot);
+TOMO_API int tomo_acc_fetch(tomo_ctx *ctx, int slot0, int n, int allreduce, double *h_out);
 
 /* ---------------------------------------------------------------- regularised solvers' vector kernels
  * tomo_vec_soft_threshold: out = x - l where x > l, x + l where x < -l, else 0 -- recon/regularized.py:433-440

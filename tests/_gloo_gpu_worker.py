@@ -91,8 +91,62 @@ class HostStagedComm(object):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t[0])
 
+    def allreduce_array(self, a):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a, np.float64))
+        self.dist.all_reduce(t)
+        a[...] = t.numpy()
+        return a
+
     def barrier(self):
         self.dist.barrier()
+
+
+def align_rigid_stages(ctx, comm, out):
+    """examples/align_rigid's outer loop on this world: the composed run, and each half against an unsharded loop on the
+    same context fed the same inputs (see tests/_gloo_worker.py for why the halves and not the composition are compared tightly)."""
+    from tomography_alignment_amd import _lib
+    from tomography_alignment_amd.backend import HipBackend
+    from tomography_alignment_amd.comm import SingleComm
+    from tomography_alignment_amd.examples import align_rigid
+    from tomography_alignment_amd.recon import sirt_mpi
+    from tomography_alignment_amd.utilities.geometry import Geometry
+    from tomography_alignment_amd.utilities.generate_phantom import shepp3d
+    N, n_proj = 48, 12
+    rng = np.random.default_rng(17)
+    x = shepp3d(N).astype(np.float32)
+    phi = np.linspace(0.0, np.pi, n_proj)
+    alpha, beta = np.deg2rad(rng.uniform(-0.8, 0.8, n_proj)), np.deg2rad(rng.uniform(-0.8, 0.8, n_proj))
+    xyz = np.zeros((n_proj, 3))
+    xyz[:, 0], xyz[:, 2] = rng.uniform(-1.5, 1.5, n_proj), rng.uniform(-1.5, 1.5, n_proj)
+    geo = Geometry(n_proj, np.array([N] * 3), np.ones(3), np.array([N, N]), np.ones(2))
+    full = HipBackend(geo, ctx=ctx)
+    b = full.forward(_lib.poses_array(phi, alpha, beta, xyz, np.zeros(3)), full.upload(x), full.empty(n_proj * N * N)).download().reshape(n_proj, N, N)
+    data = dict(projections=b, phi=phi, phantom=x, xyz=xyz, alpha=alpha, beta=beta)
+    mine = np.array_split(np.arange(n_proj), comm.size)[comm.rank]
+    shard_be = lambda: HipBackend(sirt_mpi.SIRT._shard_geometry(geo, mine), ctx=ctx)      # noqa: E731
+    comm.force_pipeline = True            # the slab pipeline (reduce-scatter / own piece / all-gather) also at world 1
+    tight = {"options": {"ftol": 1e-15, "gtol": 1e-11}}
+    rec, a, bb, t, hist = align_rigid.run(data, n_outer=2, sirt_iters=8, verbose=False, backend=shard_be(), comm=comm, align_kwargs=tight)
+    out["e_rec"], out["e_a"], out["e_b"], out["e_xyz"] = rec, a, bb, t
+    out["e_rmse"], out["e_shift_err"] = np.array([h["rmse"] for h in hist]), np.array([h["shift_err_px"] for h in hist])
+    out["e_injected"] = np.abs(xyz[:, [0, 2]]).mean()
+    out["e_spread"] = max(comm.allreduce_max(float(v)) + comm.allreduce_max(-float(v)) for v in np.concatenate([a, bb, t.ravel()]))
+    out["e_pipelined"] = bool(align_rigid.run.last_loop.solver._iter_pipelined)
+    ref = align_rigid.OuterLoop(data, backend=HipBackend(geo, ctx=ctx), comm=SingleComm())
+    shd = align_rigid.OuterLoop(data, backend=shard_be(), comm=comm)
+    for stage in (0, 1):
+        (k_r, err_r), (k_s, err_s) = ref.reconstruct(8), shd.reconstruct(8)
+        a_r, a_s = ref.download(), shd.download()
+        out["st_sirt%d_rec" % stage] = float(np.max(np.abs(a_s - a_r)) / np.max(np.abs(a_r)))
+        out["st_sirt%d_err" % stage] = float(np.max(np.abs(err_s - err_r) / err_r)) if k_r == k_s else 1.0
+        shd.d_rec.upload(a_r)
+        r_r, r_s = ref.align(**tight), shd.align(**tight)
+        out["st_align%d_x" % stage] = float(np.max(np.abs(r_s["x"] - r_r["x"])))
+        out["st_align%d_fun" % stage] = float(np.max(np.abs(r_s["fun"] - r_r["fun"]) / np.maximum(np.abs(r_r["fun"]), 1e-30)))
+        shd.alpha_rec, shd.beta_rec, shd.xyz_rec = ref.alpha_rec.copy(), ref.beta_rec.copy(), ref.xyz_rec.copy()
+    out["st_pose_moved"] = float(np.abs(ref.xyz_rec).max())
+    comm.force_pipeline = False
 
 
 def main(out_path):
@@ -137,6 +191,7 @@ def main(out_path):
             out["%s_%s_nvol" % (tag, mode)], out["%s_%s_nslab" % (tag, mode)] = comm.n_vol_allreduce - v0, comm.n_slab_allreduce - s0
             out["%s_%s_nrs" % (tag, mode)], out["%s_%s_nag" % (tag, mode)] = getattr(comm, "n_rs", 0) - r0, getattr(comm, "n_ag", 0) - a0
             out["%s_%s_pipelined" % (tag, mode)] = s._iter_pipelined
+    align_rigid_stages(ctx, comm, out)
     if comm.rank == 0:
         np.savez(out_path, **out)
     dist.barrier()

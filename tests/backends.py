@@ -48,8 +48,10 @@ class OracleBackend(object):
         self.og = orc.Geo(geometry.n_proj, np.asarray(geometry.vox_shape), np.ones(3), np.asarray(geometry.det_shape), np.ones(2),
                           step_size=geometry.step_size)
         self.calls = {"forward": 0, "adjoint": 0, "cost_grad": 0, "proj_grad": 0}
+        self.n_uploaded = 0        # float32 values that crossed "PCIe" (tests of what a rank uploads)
 
     def upload(self, host):
+        self.n_uploaded += int(np.size(host))
         return Buf(host)
 
     def download(self, buf):
@@ -198,6 +200,21 @@ class OracleBackend(object):
     def diff_sumsq(self, a, b):
         e = (a.a - b.a).astype(np.float64)
         return float(np.dot(e, e))
+
+    # device accumulators (tomo_acc_*): local sums; summing over ranks is the communicator's job here
+    def acc_zero(self, slot0, n=1):
+        if not hasattr(self, "_accs"):
+            self._accs = np.zeros(16)
+        self._accs[slot0:slot0 + n] = 0.0
+
+    def dot_acc(self, a, b, slot, diff=False):
+        if not hasattr(self, "_accs"):
+            self._accs = np.zeros(16)
+        self._accs[slot] += self.diff_sumsq(a, b) if diff else self.dot(a, b)
+
+    def acc_fetch(self, slot0, n=1, allreduce=False):
+        assert not allreduce, "the stand-in backend has no communicator of its own"
+        return self._accs[slot0:slot0 + n].copy()
 
     def sync(self):
         pass

@@ -29,7 +29,10 @@ _T_NEW_X, _T_FG, _T_CONVERGENCE, _T_STOP = 1, 3, 4, 5
 class Lbfgsb(object):
     """One L-BFGS-B minimisation in reverse communication (scipy/optimize/_lbfgsb_py.py::_minimize_lbfgsb, same defaults)."""
 
-    def __init__(self, x0, bounds=None, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5, maxfun=15000, maxiter=15000, maxls=20, **ignored):
+    def __init__(self, x0, bounds=None, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5, maxfun=15000, maxiter=15000, maxls=20, **unknown):
+        if unknown:      # scipy warns about option keys it does not know (OptimizeWarning); a misspelled `maxiter` must not pass silently here either
+            raise TypeError("L-BFGS-B reverse-communication driver: unsupported option(s) %s (supported: maxcor, ftol, gtol, maxfun, maxiter, maxls)"
+                            % sorted(unknown))
         x0 = np.asarray(x0, np.float64).ravel()
         n = x0.size
         self.m, self.n = int(maxcor), n
@@ -110,9 +113,13 @@ def minimize_many(fun_batch, x0, bounds=None, options=None, overlap=None):
     """Minimise len(x0) independent problems.  fun_batch(ids, X) -> (f[len(ids)], g[len(ids), n]) evaluates the problems `ids` at the
     rows of X.  With `overlap` (a callable taking a zero-argument function and returning an object with .result(), e.g. a one-worker
     executor's submit) the problems are split into two halves that take turns: one half is being evaluated while this thread runs
-    the other half's optimiser steps.  Returns (x, fun, nfev, status) arrays."""
+    the other half's optimiser steps; EVERY evaluation then goes through `overlap` (the tail and small problem counts too), so one
+    thread owns the device for the whole pass.  Returns (x, fun, nfev, status) arrays.
+
+    Supported scipy range: the private core `scipy.optimize._lbfgsb.setulb` with integer task arrays (scipy 1.15.x; `AVAILABLE` and
+    `self_test()` decide at run time, nothing is assumed from the version string)."""
     opts = dict(options or {})
-    for k in ("disp", "iprint", "eps", "callback", "finite_diff_rel_step"):
+    for k in ("disp", "iprint", "eps", "callback", "finite_diff_rel_step"):      # accepted by scipy's front end, meaningless with jac=True / here
         opts.pop(k, None)
     x0 = np.asarray(x0, np.float64)
     n_prob = x0.shape[0]
@@ -130,11 +137,16 @@ def minimize_many(fun_batch, x0, bounds=None, options=None, overlap=None):
         for k, i in enumerate(ids):
             st[i].feed(f[k], g[k])
 
+    def evaluate_now(w):
+        """blocking evaluation -- on the helper thread too when there is one (one thread owns the device)"""
+        X = points(w)
+        return fun_batch(w, X) if overlap is None else overlap(lambda: fun_batch(w, X)).result()
+
     ids = list(range(n_prob))
     if overlap is None or n_prob < 64:
         wait = step(ids)
         while wait:
-            give(wait, fun_batch(wait, points(wait)))
+            give(wait, evaluate_now(wait))
             wait = step(wait)
     else:
         wa, wb = step(ids[0::2]), step(ids[1::2])
@@ -147,7 +159,7 @@ def minimize_many(fun_batch, x0, bounds=None, options=None, overlap=None):
                     wa = step(wa)
                 wait = wa + wb
                 while wait:
-                    give(wait, fun_batch(wait, points(wait)))
+                    give(wait, evaluate_now(wait))
                     wait = step(wait)
                 break
             fut_b = overlap(lambda w=wb, X=points(wb): fun_batch(w, X)) if wb else None

@@ -80,6 +80,9 @@ SIGNATURES = {
     "tomo_vec_mul": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64]),
     "tomo_vec_dot": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_dp]),
     "tomo_vec_diff_sumsq": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_dp]),
+    "tomo_acc_zero": (ctypes.c_int, [_c_vp, ctypes.c_int, ctypes.c_int]),
+    "tomo_vec_dot_acc": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, ctypes.c_int]),
+    "tomo_acc_fetch": (ctypes.c_int, [_c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp]),
     "tomo_vec_soft_threshold": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_float]),
     "tomo_tv_denoise_fista": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
                                              ctypes.c_int, ctypes.POINTER(ctypes.c_int), _c_dp]),

@@ -45,15 +45,32 @@ _GRAD_ROW = {"x": 0, "y": 1, "z": 2, "p": 3, "a": 4, "b": 5}
 
 
 class BatchEvaluator(object):
-    """cost / gradient of many projections per launch, volume and measured projections resident in HBM."""
+    """cost / gradient of many projections per launch, volume and measured projections resident in HBM.
 
-    def __init__(self, backend, rec, projections, cor_shift=None, trace=None):
+    Only the measured rows this evaluator will ever be asked about go to the device (`indices`: a rank of a sharded pass uploads its own
+    np.array_split block, not all n_proj rows -- 4.3 GB per rank at 1024^2 x 1024 otherwise); `projections` may also BE a device table
+    already holding exactly those rows, in the order of `indices` (the sharded solver's own rows: nothing crosses PCIe)."""
+
+    def __init__(self, backend, rec, projections, cor_shift=None, trace=None, indices=None, n_all=None):
         self.be = backend
-        self.trace = trace      # a list: every launch's (projection indices, poses) is appended (bench.py replays them in full batches)
+        self.trace = trace      # a list: every launch's (table rows, poses) is appended (bench.py replays them in full batches)
         self.vol = rec if backend.is_buffer(rec) else backend.upload(np.asarray(rec, np.float32).ravel())
-        b = np.asarray(projections, np.float32)
-        self.n = b.shape[0]
-        self._b_all = backend.upload(b.reshape(self.n, -1))
+        if backend.is_buffer(projections):
+            if indices is None or n_all is None:
+                raise ValueError("BatchEvaluator: a device table of measured rows needs `indices` (the projections its rows belong to) and `n_all`")
+            indices = np.asarray(indices, np.int64)
+            if projections.size != indices.size * backend.n_det:
+                raise ValueError("BatchEvaluator: device table has %d values for %d rows of %d" % (projections.size, indices.size, backend.n_det))
+            self.n = int(n_all)
+            self._b_all = projections
+        else:
+            b = np.asarray(projections, np.float32)
+            self.n = b.shape[0]
+            indices = np.arange(self.n) if indices is None else np.asarray(indices, np.int64)
+            b = b.reshape(self.n, -1)
+            self._b_all = backend.upload(b if indices.size == self.n and np.array_equal(indices, np.arange(self.n)) else b[indices])
+        self.row_of = np.full(self.n, -1, np.int64)      # projection index -> row of the device table (-1: not resident)
+        self.row_of[indices] = np.arange(indices.size)
         self.cor = np.zeros(self.n) if cor_shift is None else np.asarray(cor_shift, np.float64).reshape(self.n, -1)[:, 0]
         self._staged = False
         self.n_launch = 0
@@ -64,15 +81,18 @@ class BatchEvaluator(object):
         """idx: projection indices (m,), poses6: (m,6) rows (phi, alpha, beta, tx, ty, tz) -> cost[m], grad6[m,6]."""
         idx = np.asarray(idx, np.int64)
         m = idx.size
+        rows = self.row_of[idx]
+        if m and rows.min() < 0:
+            raise ValueError("BatchEvaluator: projection %d is not among the rows this evaluator holds" % int(idx[np.argmin(rows)]))
         poses = np.zeros((m, _lib.POSE_STRIDE), np.float64)
         poses[:, :6] = poses6
         poses[:, 6] = self.cor[idx]
         self.n_launch += 1
         self.n_eval += m
         if self.trace is not None:
-            self.trace.append((idx.copy(), poses.copy()))
+            self.trace.append((rows.copy(), poses.copy()))
         t0 = time.perf_counter()
-        out = self.be.cost_grad(np.ascontiguousarray(poses), self.vol, self._b_all, rows=idx)   # measured rows stay in HBM
+        out = self.be.cost_grad(np.ascontiguousarray(poses), self.vol, self._b_all, rows=rows)   # measured rows stay in HBM
         if not self._staged:                    # self.vol is pinned until close(): its zero-padded copy is staged once
             self._staged = True
             ctx = getattr(self.be, "ctx", None)
@@ -167,6 +187,9 @@ class _Scheduler(object):
                     self.events[i].set()
 
 
+_WARNED_FALLBACK = False
+
+
 def align_projections(backend, rec, projections, phi, letters="xzab", x0=None, angles0=None, xyz0=None, cor_shift=None,
                       bounds=None, scale_factor=None, options=None, indices=None, max_threads=256, driver="auto", trace=None):
     """Align many projections at once.
@@ -176,10 +199,16 @@ def align_projections(backend, rec, projections, phi, letters="xzab", x0=None, a
     x0        (n, len(letters)) start values (default 0); angles0 (n,3) fixed (phi,alpha,beta) offsets (default
               phi from `phi`, 0, 0); xyz0 (n,3) fixed translations.
     bounds    per-parameter (lo, hi) pairs as scipy takes them (examples/align_rigid.py:48 uses +-3 px / +-0.02 rad).
+    projections   host array of ALL measured projections (n, ...) -- only the rows `indices` names are uploaded -- or a device table
+              that already holds exactly the rows of `indices`, in that order.
+    indices   the projections to align (default all); the other rows of the returned tables stay zero.
     Returns dict(x=(n,k), fun=(n,), nfev=(n,), n_launch, n_eval).
     """
-    b = np.asarray(projections, np.float32)
-    n_all = b.shape[0]
+    n_all = int(np.size(phi))
+    if not backend.is_buffer(projections):
+        projections = np.asarray(projections, np.float32)
+        if projections.shape[0] != n_all:
+            raise ValueError("align_projections: %d projections for %d angles" % (projections.shape[0], n_all))
     indices = np.arange(n_all) if indices is None else np.asarray(indices, np.int64)
     k = len(letters)
     cols = [_POSE_COL[c] for c in letters]
@@ -192,7 +221,7 @@ def align_projections(backend, rec, projections, phi, letters="xzab", x0=None, a
     if xyz0 is not None:
         base[:, 3:6] = np.asarray(xyz0, np.float64)
     x0 = np.zeros((n_all, k)) if x0 is None else np.asarray(x0, np.float64).reshape(n_all, k)
-    ev = BatchEvaluator(backend, rec, b, cor_shift, trace=trace)
+    ev = BatchEvaluator(backend, rec, projections, cor_shift, trace=trace, indices=indices, n_all=n_all)
     out_x, out_f, out_n = np.zeros((n_all, k)), np.zeros(n_all), np.zeros(n_all, np.int64)
     opts = {"disp": False}
     opts.update(options or {})
@@ -213,7 +242,8 @@ def align_projections(backend, rec, projections, phi, letters="xzab", x0=None, a
 
         t0 = time.perf_counter()
         ctx = getattr(backend, "ctx", None)
-        # the helper thread is the only one that touches the GPU while the pass runs; HIP's current device is per thread
+        # the helper thread is the only one that touches the GPU while the pass runs -- minimize_many sends EVERY evaluation through
+        # `overlap`, the tail and small problem counts included; HIP's current device is per thread, so that thread binds it once
         with ThreadPoolExecutor(max_workers=1, initializer=(ctx.make_current if ctx is not None else None)) as pool:
             try:
                 x, f, nf, _ = _lbfgsb_batch.minimize_many(fun_batch, x0[order], bounds=bounds, options=opts, overlap=pool.submit)
@@ -223,6 +253,12 @@ def align_projections(backend, rec, projections, phi, letters="xzab", x0=None, a
         return {"x": out_x, "fun": out_f, "nfev": out_n, "n_launch": ev.n_launch, "n_eval": ev.n_eval, "t_eval": ev.t_eval,
                 "driver": "batch", "wall_s": time.perf_counter() - t0}
 
+    global _WARNED_FALLBACK
+    if driver != "threads" and not _WARNED_FALLBACK:
+        _WARNED_FALLBACK = True
+        import warnings
+        warnings.warn("align_projections: this scipy's private L-BFGS-B core does not have the layout _lbfgsb_batch.py was written against "
+                      "(scipy 1.15.x); falling back to one optimize.minimize per worker thread (same results, slower host side)", RuntimeWarning)
     # a fixed pool of worker threads (at most max_threads): each runs one projection's optimiser at a time and takes the next
     # projection from the queue when it converges, so the batches stay full until the very end instead of draining once per
     # chunk -- and 720 projections cost 256 threads, not 720
@@ -278,12 +314,18 @@ def align_projections(backend, rec, projections, phi, letters="xzab", x0=None, a
 
 
 def align_projections_sharded(comm, backend, rec, projections, phi, **kw):
-    """Rank r aligns its np.array_split block of the projections; every rank returns the full (n, k) table."""
-    n = np.asarray(projections).shape[0]
+    """Rank r aligns its np.array_split block of the projections; every rank returns the full (n, k) table.
+    `projections`: the host array of all measured projections (only the rank's own rows are uploaded) or a device table holding
+    exactly the rank's own rows (the sharded solver's `d_b`)."""
+    n = int(np.size(phi))
     size = comm.Get_size() if hasattr(comm, "Get_size") else comm.size
     rank = comm.Get_rank() if hasattr(comm, "Get_rank") else comm.rank
     mine = np.array_split(np.arange(n), size)[rank]
-    res = align_projections(backend, rec, projections, phi, indices=mine, **kw)
+    if mine.size:
+        res = align_projections(backend, rec, projections, phi, indices=mine, **kw)
+    else:       # more ranks than projections: nothing to align here, but the table all-reduce below is issued by every rank
+        k0 = len(kw.get("letters", "xzab"))
+        res = {"x": np.zeros((n, k0)), "fun": np.zeros(n), "nfev": np.zeros(n, np.int64), "n_launch": 0, "n_eval": 0}
     k = res["x"].shape[1]
     table = np.zeros((n, k + 2))
     table[mine, :k] = res["x"][mine]
@@ -291,5 +333,6 @@ def align_projections_sharded(comm, backend, rec, projections, phi, **kw):
     table[mine, k + 1] = res["nfev"][mine]
     if size > 1:
         comm.allreduce_array(table)                      # tiny: k + 2 numbers per projection, zero outside the own block
-    return {"x": table[:, :k], "fun": table[:, k], "nfev": table[:, k + 1].astype(np.int64), "n_launch": res["n_launch"],
-            "n_eval": res["n_eval"]}
+    out = dict(res)
+    out.update({"x": table[:, :k], "fun": table[:, k], "nfev": table[:, k + 1].astype(np.int64)})
+    return out

@@ -246,6 +246,25 @@ class HipBackend(object):
         self.ctx.check(self.lib.tomo_vec_diff_sumsq(self.ctx.handle, a.ptr, b.ptr, a.size, ctypes.byref(s)))
         return s.value
 
+    # ---- device accumulators: several scalars of an iteration, one host synchronisation (include/tomo.h tomo_acc_*)
+    N_ACC = 16
+
+    def acc_zero(self, slot0, n=1):
+        self.ctx.check(self.lib.tomo_acc_zero(self.ctx.handle, int(slot0), int(n)))
+
+    def dot_acc(self, a, b, slot, diff=False):
+        """slot += sum(a*b)  (diff: sum((a-b)^2)); nothing comes back to the host."""
+        if a.size != b.size:
+            raise ValueError("dot_acc: operand sizes differ")
+        self.ctx.check(self.lib.tomo_vec_dot_acc(self.ctx.handle, a.ptr, b.ptr, a.size, 1 if diff else 0, int(slot)))
+
+    def acc_fetch(self, slot0, n=1, allreduce=False):
+        """-> the n accumulators from slot0 on; allreduce: summed over the ranks of the context's RCCL communicator first (one small
+        device-side collective)."""
+        out = np.zeros(int(n), np.float64)
+        self.ctx.check(self.lib.tomo_acc_fetch(self.ctx.handle, int(slot0), int(n), 1 if allreduce else 0, _lib.dptr(out)))
+        return out
+
     # ---- regularised solvers' vector kernels (recon/regularized.py:433, utilities/tv_denoise.py:98-170)
     def soft_threshold(self, out, x, lam):
         self.ctx.check(self.lib.tomo_vec_soft_threshold(self.ctx.handle, out.ptr, x.ptr, x.size, float(lam)))

@@ -155,6 +155,8 @@ class SingleComm(object):
 
 class RcclComm(object):
 
+    device_scalars = True      # HipBackend.acc_fetch(allreduce=True) sums device accumulators over THIS communicator (tomo_acc_fetch)
+
     def __init__(self, ctx, rank, size, id_bytes):
         self.ctx = ctx
         self.rank = int(rank)

@@ -54,6 +54,9 @@ struct tomo_ctx {
     double *d_red = nullptr;
     double *h_red = nullptr;
     size_t red_cap = 0;     // doubles
+    // TOMO_N_ACC double accumulators (tomo_acc_zero / tomo_vec_dot_acc / tomo_acc_fetch) + their pinned host mirror
+    double *d_acc = nullptr;
+    double *h_acc = nullptr;
     // live-block list of the flat forward (grow-only): [0] = number of live blocks, [1 ..] their ids in launch order, then one flag byte per block
     int *d_blk = nullptr;
     size_t blk_ints = 0;

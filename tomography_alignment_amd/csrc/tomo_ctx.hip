@@ -65,6 +65,8 @@ extern "C" int tomo_ctx_destroy(tomo_ctx *c)
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_red) (void)hipFree(c->d_red);
     if (c->h_red) (void)hipHostFree(c->h_red);
+    if (c->d_acc) (void)hipFree(c->d_acc);
+    if (c->h_acc) (void)hipHostFree(c->h_acc);
     if (c->d_ws) (void)hipFree(c->d_ws);
     tomo_csr_release(c);
     if (c->d_blk) (void)hipFree(c->d_blk);
@@ -801,6 +803,55 @@ extern "C" int tomo_comm_join(tomo_ctx *ctx)
     ctx->comm_done.clear();
     for (auto e : ctx->comm_done_g) ctx->comm_ev_pool.push_back(e);
     ctx->comm_done_g.clear();
+    return TOMO_OK;
+}
+
+// ---- device accumulators (include/tomo.h: tomo_acc_*): scalars of a solver iteration with one host synchronisation
+static int acc_ensure(tomo_ctx *ctx)
+{
+    if (ctx->d_acc) return TOMO_OK;
+    TOMO_HIP(ctx, hipSetDevice(ctx->device));
+    TOMO_HIP(ctx, hipMalloc((void **)&ctx->d_acc, TOMO_N_ACC * sizeof(double)));
+    TOMO_HIP(ctx, hipHostMalloc((void **)&ctx->h_acc, TOMO_N_ACC * sizeof(double), hipHostMallocDefault));
+    TOMO_HIP(ctx, hipMemsetAsync(ctx->d_acc, 0, TOMO_N_ACC * sizeof(double), ctx->stream));
+    return TOMO_OK;
+}
+
+extern "C" int tomo_acc_zero(tomo_ctx *ctx, int slot0, int n)
+{
+    if (!ctx || slot0 < 0 || n < 0 || slot0 + n > TOMO_N_ACC) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_acc_zero: bad slots");
+    int rc = acc_ensure(ctx);
+    if (rc) return rc;
+    if (n) TOMO_HIP(ctx, hipMemsetAsync(ctx->d_acc + slot0, 0, n * sizeof(double), ctx->stream));
+    return TOMO_OK;
+}
+
+extern "C" int tomo_vec_dot_acc(tomo_ctx *ctx, const float *a, const float *b, int64_t n, int diff, int slot)
+{
+    if (!ctx || slot < 0 || slot >= TOMO_N_ACC || n < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_vec_dot_acc: bad args");
+    int rc = acc_ensure(ctx);
+    if (rc) return rc;
+    if (n == 0) return TOMO_OK;
+    if (!a || !b) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_vec_dot_acc: null operand");
+    TOMO_LAUNCH(ctx, "k_dot", k_dot, dim3(vec_grid(n)), dim3(256), 0, a, b, n, diff ? 1 : 0, ctx->d_acc + slot);
+    return TOMO_OK;
+}
+
+extern "C" int tomo_acc_fetch(tomo_ctx *ctx, int slot0, int n, int allreduce, double *h_out)
+{
+    if (!ctx || !h_out || slot0 < 0 || n < 0 || slot0 + n > TOMO_N_ACC) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_acc_fetch: bad args");
+    int rc = acc_ensure(ctx);
+    if (rc) return rc;
+    if (n == 0) return TOMO_OK;
+    if (allreduce && ctx->comm) {
+        tomo_prof_begin(ctx, "allreduce_scalars");
+        ncclResult_t r = ncclAllReduce(ctx->d_acc + slot0, ctx->d_acc + slot0, (size_t)n, ncclFloat64, ncclSum, ctx->comm, ctx->stream);
+        tomo_prof_end(ctx);
+        if (r != ncclSuccess) return tomo_fail(ctx, TOMO_ERR_RCCL, std::string("ncclAllReduce (accumulators): ") + ncclGetErrorString(r));
+    }
+    TOMO_HIP(ctx, hipMemcpyAsync(ctx->h_acc + slot0, ctx->d_acc + slot0, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; ++i) h_out[i] = ctx->h_acc[slot0 + i];
     return TOMO_OK;
 }
 

@@ -91,10 +91,13 @@ class CGLS(object):
         conv = np.zeros((niter,))
         self.rms_error = np.zeros((niter,))
         while k < niter:
-            self.proj_mat.apply(self.d_p, self.d_q)                                          # r = A p       :54
-            alpha = self._gamma / self._allreduce_scalar(be.dot(self.d_q, self.d_q))         # :56
+            self._apply_to_p()                                                               # r = A p       :54
+            qq, conv_sumsq = self._q_norms()                                                 # :56 (cgls_mpi.py:72-76: the monitor too)
+            alpha = self._gamma / qq
             be.axpy(self.d_rec, self.d_p, alpha)                                             # :57
-            conv[k] = np.sqrt(self._allreduce_scalar(self._conv_sumsq()))                    # :58-59
+            if conv_sumsq is None:
+                conv_sumsq = self._conv_sumsq()                                              # :58-59: ||b - A rec|| of the UPDATED rec
+            conv[k] = np.sqrt(conv_sumsq)
             if k > 0 and conv[k] > conv[k - 1]:
                 print('reinitializing at iteration %d' % k)
                 if reinit_iter + 1 == k:
@@ -108,18 +111,36 @@ class CGLS(object):
                 be.copy(self.d_q, q_keep)
                 reinit_iter = k
             be.axpy(self.d_r, self.d_q, -alpha)                                              # _r -= alpha r  :70
-            self._allreduce_vol(self.proj_mat.T.apply(self.d_r, self.d_s))                   # p = A^T _r     :72
-            gamma = be.dot(self.d_s, self.d_s)
+            gamma, rr = self._backproject_and_norms(self.ground_truth is None)               # p = A^T _r :72 ; ||p||^2 ; ||_r||^2 (:80)
             beta = gamma / self._gamma
             self._gamma = gamma
-            be.xpay(self.d_p, self.d_s, beta)                                                # _p = p + beta _p   :78
+            self._update_p(beta, last=(k + 1 >= niter))                                      # _p = p + beta _p   :78
             if self.ground_truth is None:
-                self.rms_error[k] = np.sqrt(self._allreduce_scalar(be.dot(self.d_r, self.d_r))) / norm_factor   # :80
+                self.rms_error[k] = np.sqrt(rr) / norm_factor                                # :80
             else:
                 self.rms_error[k] = np.sqrt(be.diff_sumsq(self.d_rec, self.d_gt)) / norm_factor                # :82
             k += 1
         self.rec = be.download(self.d_rec) if _download else self.rec
         return self.rec, self.rms_error[:k]
+
+    # ---- the steps the angle-sharded subclass replaces (recon/cgls_mpi.py)
+    def _apply_to_p(self):
+        """d_q = A d_p."""
+        self.proj_mat.apply(self.d_p, self.d_q)
+
+    def _q_norms(self):
+        """(||A p||^2, the convergence monitor's sum of squares when it is a function of A p alone -- recon/cgls_mpi.py:74 -- else None:
+        recon/cgls.py:58 monitors ||b - A rec|| of the rec updated with this very alpha, see _conv_sumsq)."""
+        return self.be.dot(self.d_q, self.d_q), None
+
+    def _backproject_and_norms(self, want_rr):
+        """d_s = A^T d_r; -> (||d_s||^2, ||d_r||^2 or None)."""
+        be = self.be
+        self.proj_mat.T.apply(self.d_r, self.d_s)
+        return be.dot(self.d_s, self.d_s), (be.dot(self.d_r, self.d_r) if want_rr else None)
+
+    def _update_p(self, beta, last=False):
+        self.be.xpay(self.d_p, self.d_s, beta)
 
     def _conv_sumsq(self):
         """||b - A rec||^2 (recon/cgls.py:58-59); costs one extra forward projection, as in the reference."""
