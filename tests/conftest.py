@@ -14,6 +14,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _close_contexts_a_test_leaves_behind():
+    """Every `HipBackend(geo)` / `_lib.Context()` a test opens has a stream, events and workspaces of its own; a hundred tests in one
+    process left a hundred of them open, and late tests found their streams sharing hardware queues (the
+    stream-overlap control could no longer race).  What a test opened is closed when it returns -- device memory included; contexts of
+    wider-scoped fixtures (opened before the test function's own fixtures) stay."""
+    try:
+        from tomography_alignment_amd import _lib
+    except Exception:      # noqa: BLE001
+        yield
+        return
+    before = set(_lib.LIVE_CONTEXTS)
+    yield
+    for c in [c for c in list(_lib.LIVE_CONTEXTS) if c not in before]:
+        try:
+            c.close()
+        except Exception:      # noqa: BLE001
+            pass
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

@@ -40,6 +40,10 @@ def test_bench_json_contract():
     a = d["alignment_gradient"]
     assert a["evals_per_sec"] > 0 and a["dense_volume"]["evals_per_sec"] > 0
     assert d["dense_volume"]["value"] > 0 and d["tilted_poses"]["value"] > 0
+    # config 5 end to end: two outer iterations, the second one's SIRT at the recovered (tilted) poses
+    e = d["align_rigid_e2e"]
+    assert len(e["outer"]) == 2 and e["sharded_code_path"] is False and e["outer"][1]["sirt_wall_s"] > 0 and e["alignment_evals"] > 0
+    assert d["cgls"]["value"] > 0 and d["cgls"]["pipelined"] is False
 
 
 def test_bench_gpus_2_on_a_one_gpu_box_fails_cleanly():
@@ -54,6 +58,22 @@ def test_bench_gpus_2_on_a_one_gpu_box_fails_cleanly():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "64", "--angles", "48"], capture_output=True, text=True,
                          timeout=600, cwd=ROOT)
     assert out.returncode == 2 and "2 GPUs requested, %d visible" % n.value in out.stderr and out.stdout.strip() == ""
+
+
+def test_bench_sharded_legs_print_the_same_keys_as_the_plain_run():
+    """`bench.py --gpus 1 --force-sharded` runs every leg a `--gpus 8` run will -- SIRT, dense / tilted side runs, CGLS
+    (sharded, pipelined), alignment gradient, align_rigid end to end through sirt_mpi.SIRT + align_projections_sharded -- and prints the
+    key set of the plain run."""
+    plain = _run(["--no-cpu-baseline"])
+    shard = _run(["--no-cpu-baseline", "--force-sharded"])
+    assert set(shard) == set(plain), set(shard) ^ set(plain)
+    e = shard["align_rigid_e2e"]
+    assert e["sharded_code_path"] is True and e["ranks"] == 1 and len(e["outer"]) == 2 and set(e) == set(plain["align_rigid_e2e"])
+    assert shard["cgls"]["pipelined"] is True and shard["cgls"]["value"] > 0 and "reduce_scatter_f32_ms_per_step" in shard["cgls"]
+    assert "reduce_scatter_f32" in shard["kernels"] and "reduce_scatter_f32" not in plain["kernels"]
+    # the sharded loop at world 1 = the plain loop up to float32 sums in another order (first outer iteration: before the optimiser's
+    # sensitivity enters, tests/test_dist_gloo.py)
+    assert abs(e["outer"][0]["rmse_after_sirt"] / plain["align_rigid_e2e"]["outer"][0]["rmse_after_sirt"] - 1) < 1e-4
 
 
 def test_bench_sharded_code_path_on_one_gpu():

@@ -1,7 +1,7 @@
 """GPU tests of the layers above the projectors: device-resident SIRT / CGLS, the alignment API, solver vector
 kernels, the device phantom, event timing, and RCCL bring-up (1 rank) -- all through the C-ABI."""
 import copy
-
+import os
 import time
 
 import numpy as np
@@ -272,28 +272,9 @@ def test_pipelined_allreduce_path_matches_plain(shepp32):
         assert rel_max(res[True][0], res[False][0]) < 2e-6 and np.allclose(res[True][1], res[False][1], rtol=1e-6)
     be = HipBackend(geo, ctx=ctx)
     assert be.xslab_info() == (3, 16)
-    # The test hook that gives a ONE-rank run teeth (csrc/tomo_ctx.hip::comm_async): with comm_test_poison_us > 0 the
-    # communication stream doubles a collective's buffer, idles, and halves it again before the collective runs -- a compute-stream
-    # kernel that touches the buffer without having waited sees doubled values.  Control first: the same read with and without the wait.
-    v = be.upload(np.full(4096, 3.0, np.float32))
-    ctx.set_option("comm_test_poison_us", 30000)
-    comm.allreduce_sum_async(v)
-    time.sleep(0.01)                                  # the doubling kernel has run, the idle kernel is running
-    unwaited = be.dot(v, v)                           # NOT waited for: reads the doubled buffer (be.dot synchronises the compute stream only)
-    comm.allreduce_sum_async(v)
-    comm.wait_next()
-    comm.wait_next()
-    waited = be.dot(v, v)
-    comm.join()
-    ctx.set_option("comm_test_poison_us", 0)
-    assert waited == 4096 * 9.0, (unwaited, waited)
-    # The un-waited read sees the doubled buffer only if the two streams really run side by side.  They do when they sit on hardware queues
-    # of their own (GPU call r4b: 4x, as designed); a process that has opened many contexts (this test process, late in the suite) can find
-    # both streams on ONE hardware queue, where the device itself serialises them and no race is possible (GPU call r4e: 1x).  Reported,
-    # not asserted: either way the poisoned solver runs below must equal the plain sequence.
-    assert unwaited in (4096 * 36.0, 4096 * 9.0), (unwaited, waited)
-    print("comm_test_poison control: un-waited read saw %s values" % ("DOUBLED (streams concurrent: the hook has teeth here)" if unwaited == 4096 * 36.0
-                                                                      else "restored (streams serialised on one hardware queue in this process)"))
+    # (The control of the poison hook -- an un-waited read MUST see the doubled buffer -- and the mutation "a wait goes missing" run in a
+    #  fresh child process, test_stream_overlap_waits_have_teeth below: in this process, late in the suite, the two streams may share one
+    #  hardware queue, where nothing can race.  Here the poisoned runs only have to equal the plain sequence.)
     # round 3: the NEXT iteration's forward projection is made slab by slab behind the update (tomo_forward_xslab, tomo_comm_wait_next).
     # A ragged volume with 6 tile columns, flat and tilted poses, positivity and a ground truth (the error sum accumulates over the
     # slabs on the device); per iteration every slab's all-reduce is waited for once and iterations 2.. launch no whole forward.
@@ -350,6 +331,36 @@ def test_pipelined_allreduce_path_matches_plain(shepp32):
             assert rel_max(got[0], ref[0]) < 2e-6 and np.allclose(got[1], ref[1], rtol=1e-6), (tilt, key)
         assert ref[1][-1] < ref[1][0]
     comm.close()
+
+
+@pytest.mark.timeout(900)
+def test_stream_overlap_waits_have_teeth(capsys):
+    """the stream-overlap machinery of the sharded solvers (per-collective events, tomo_comm_wait_next /
+    _wait_next_gather, the next forward projection behind in-flight all-gathers) checked where it CAN race -- a fresh child process
+    whose only context owns its hardware queues (tests/_poison_child.py): (1) the control is an assertion: an un-waited read sees the
+    doubled buffer; (2) poisoned pipelined SIRT and CGLS equal the plain sequences; (3) with ONE wait dropped they do not."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_poison_child.py")], capture_output=True, text=True, timeout=800,
+                       env=dict(os.environ, NCCL_SOCKET_IFNAME=os.environ.get("NCCL_SOCKET_IFNAME", "lo")))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    out = json.loads(lines[-1])
+    try:      # kept for the round's profiles/ (the GPU box merges gpurun_out/ back)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "poison_child_last.json"), "w") as f:
+            f.write(lines[-1] + "\n")
+    except OSError:
+        pass
+    with capsys.disabled():
+        print("overlap control in a fresh process: un-waited read %.0f (doubled: %.0f), waited %.0f; poisoned solvers worst rel %.1e; "
+              "least deviation with one wait dropped %.1e" % (out["unwaited"], 4096 * 36.0, out["waited"], out["poisoned_worst_rel"], out["wait_dropped_least_rel"]))
+    assert out["control_ok"], (out["unwaited"], out["waited"])
+    assert out["solvers_ok"], [c for c in out["cases"] if c[4] == "poisoned"]
+    assert out["mutation_ok"], [c for c in out["cases"] if c[4] != "poisoned"]
+    assert r.returncode == 0
 
 
 def test_volume_residency_is_explicit(shepp32):

@@ -8,6 +8,7 @@ utilities/ray_voxel_utilities.py:3.)
 import ctypes
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -149,10 +150,15 @@ def _ptr(x):
     return x
 
 
+LIVE_CONTEXTS = weakref.WeakSet()      # every open Context of this process (tests close what a test leaves behind, tests/conftest.py)
+
+
 class Context(object):
-    """One tomo_ctx: one GPU, one HIP stream.  All device memory of the package hangs off it."""
+    """One tomo_ctx: one GPU, one HIP stream.  All device memory of the package hangs off it: close() frees the DeviceArrays still
+    alive on it, then the context's own streams, events and workspaces."""
 
     def __init__(self, device=None):
+        self._arrays = weakref.WeakSet()
         self.lib = load()
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
@@ -167,6 +173,7 @@ class Context(object):
         self._h = h
         self.device = int(device) % n.value
         self._geom_key = None
+        LIVE_CONTEXTS.add(self)
 
     def check(self, rc, h="self"):
         if rc != 0:
@@ -176,8 +183,11 @@ class Context(object):
 
     def close(self):
         if getattr(self, "_h", None) is not None:
+            for a in list(getattr(self, "_arrays", ())):      # buffers that outlive the context would never be freed (free() needs the handle)
+                a.free()
             self.lib.tomo_ctx_destroy(self._h)
             self._h = None
+            LIVE_CONTEXTS.discard(self)
 
     def __del__(self):
         try:
@@ -264,6 +274,7 @@ class DeviceArray(object):
         ctx.check(ctx.lib.tomo_malloc(ctx.handle, self.nbytes, ctypes.byref(p)))
         self.ptr = p
         self._owner = True
+        ctx._arrays.add(self)
 
     def upload(self, host):
         host = np.ascontiguousarray(host, dtype=self.dtype)

@@ -27,7 +27,7 @@ _ctx = None
 
 def _context():
     global _ctx
-    if _ctx is None:
+    if _ctx is None or _ctx._h is None:      # closed behind our back (a test harness closing what a test opened): open another
         _ctx = _lib.Context()
     return _ctx
 

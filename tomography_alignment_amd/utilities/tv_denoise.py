@@ -20,6 +20,8 @@ def _context(ctx=None):
     global _ctx
     if ctx is not None:
         return ctx
+    if _ctx is not None and _ctx._h is None:      # closed behind our back: open another
+        _ctx = None
     if _ctx is None:
         import atexit
         _ctx = _lib.Context()          # raises without a GPU: no CPU fallback

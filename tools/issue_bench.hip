@@ -20,14 +20,15 @@
 
 enum Op { FMA, PK_FMA, ADD_U32, ADD64, READLANE, CVT, MUL_LO, MAD_U24, DPP_MOV, FLOOR, FRACT, CNDMASK, CNDMASK_IND, CNDMASK_SGPR, MUL_HI_I32, MUL_HI_U32, MIN_U32,
           CVT_RPI, PK_MUL, LSHL_ADD, BFE_I32, CMP_LT, MIX_FMA_CND, CVT_FLR, MED3, CND_DPP, ADD64_ONE, PERMUTE,
-          DS_READ_B32, DS_READ2_B32, DS_READ2ST64, DS_READ_B64, DS_READ_B128, DS_ADD_U32, DS_ADD_U64, DS_ADD_F32, DS_WRITE_B32, N_OPS };
+          DS_READ_B32, DS_READ2_B32, DS_READ2ST64, DS_READ_B64, DS_READ_B128, DS_ADD_U32, DS_ADD_U64, DS_ADD_F32, DS_WRITE_B32, DS_ADD_F32_ZERO, DS_ADD_F32_HALF, DS_ADD_RTN_F32, DS_MAX_F32, DS_ADD_F64, N_OPS };
 static const char *op_name[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_add_u32", "v_add_co+v_addc (64-bit add)", "v_readlane_b32", "v_cvt_f32_u32",
                                      "v_mul_lo_u32", "v_mad_u32_u24", "v_mov_b32 dpp wave_shl:1", "v_floor_f32", "v_fract_f32", "v_cndmask_b32",
                                      "v_cndmask_b32 (indep. dst, vcc set)", "v_cndmask_b32 (sgpr-pair mask)", "v_mul_hi_i32", "v_mul_hi_u32", "v_min_u32",
                                      "v_cvt_rpi_i32_f32", "v_pk_mul_f32", "v_lshl_add_u32", "v_bfe_i32", "v_cmp_lt_u32 (to sgpr pair)",
                                      "3 v_fma_f32 + 1 v_cndmask vcc", "v_cvt_flr_i32_f32", "v_med3_i32", "v_cndmask_b32_dpp wave_shl:1 (vcc)", "v_lshl_add_u64 (v + s pair)",
                                      "ds_permute_b32", "ds_read_b32", "ds_read2_b32", "ds_read2st64_b32", "ds_read_b64", "ds_read_b128",
-                                     "ds_add_u32", "ds_add_u64", "ds_add_f32", "ds_write_b32"};
+                                     "ds_add_u32", "ds_add_u64", "ds_add_f32", "ds_write_b32",
+                                     "ds_add_f32 (+0.0 onto zeros)", "ds_add_f32 (+0.5, sums stay < 2^24)", "ds_add_rtn_f32", "ds_max_f32", "ds_add_f64"};
 
 template <int OP>
 __global__ __launch_bounds__(256) void k_issue(int iters, unsigned long long *cycles, float *sink)
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(256) void k_issue(int iters, unsigned long long *cy
     f4 q0 = {0, 0, 0, 0}, q1 = q0;
     unsigned u0 = lane, u1 = lane + 1, u2 = lane + 2, u3 = lane + 3;
     unsigned long long w0 = lane, w1 = lane * 3;
+    double d0 = 1.0;
     int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     unsigned long long msk = __ballot(lane & 1), m0 = 0, m1 = 0;
     asm volatile("v_cmp_lt_u32 vcc, 7, %0" : : "v"(lane) : "vcc");
@@ -161,6 +163,22 @@ __global__ __launch_bounds__(256) void k_issue(int iters, unsigned long long *cy
         } else if (OP == DS_ADD_F32) {
             R4(asm volatile("ds_add_f32 %0, %1\n ds_add_f32 %0, %1 offset:256\n ds_add_f32 %0, %1 offset:512\n ds_add_f32 %0, %1 offset:768\n" : : "v"(base), "v"(a1) : "memory");)
             asm volatile("s_waitcnt lgkmcnt(0)");
+        } else if (OP == DS_ADD_F32_ZERO || OP == DS_ADD_F32_HALF) {
+            // round 5: is ds_add_f32's 768 cycles a property of the operands?  LDS is zeroed above and every operand is finite and
+            // normal in all three variants: +1.0 (DS_ADD_F32; sums reach 32 000), +0.0 (sums stay 0), +0.5 (sums reach 16 000)
+            const float inc = OP == DS_ADD_F32_ZERO ? 0.0f : 0.5f;
+            R4(asm volatile("ds_add_f32 %0, %1\n ds_add_f32 %0, %1 offset:256\n ds_add_f32 %0, %1 offset:512\n ds_add_f32 %0, %1 offset:768\n" : : "v"(base), "v"(inc) : "memory");)
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        } else if (OP == DS_ADD_RTN_F32) {
+            R4(asm volatile("ds_add_rtn_f32 %0, %4, %5\n ds_add_rtn_f32 %1, %4, %5 offset:256\n ds_add_rtn_f32 %2, %4, %5 offset:512\n ds_add_rtn_f32 %3, %4, %5 offset:768\n"
+                            : "=v"(a0), "=v"(a5), "=v"(a6), "=v"(a7) : "v"(base), "v"(a1) : "memory");)
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        } else if (OP == DS_MAX_F32) {
+            R4(asm volatile("ds_max_f32 %0, %1\n ds_max_f32 %0, %1 offset:256\n ds_max_f32 %0, %1 offset:512\n ds_max_f32 %0, %1 offset:768\n" : : "v"(base), "v"(a1) : "memory");)
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        } else if (OP == DS_ADD_F64) {
+            R4(asm volatile("ds_add_f64 %0, %1\n ds_add_f64 %0, %1 offset:512\n ds_add_f64 %0, %1 offset:1024\n ds_add_f64 %0, %1 offset:1536\n" : : "v"(base8), "v"(d0) : "memory");)
+            asm volatile("s_waitcnt lgkmcnt(0)");
         } else if (OP == DS_WRITE_B32) {
             R4(asm volatile("ds_write_b32 %0, %1\n ds_write_b32 %0, %1 offset:256\n ds_write_b32 %0, %1 offset:512\n ds_write_b32 %0, %1 offset:768\n" : : "v"(base), "v"(a1) : "memory");)
             asm volatile("s_waitcnt lgkmcnt(0)");
@@ -226,5 +244,6 @@ int main()
     run<PERMUTE>(n_cu, clk);
     run<DS_READ_B32>(n_cu, clk); run<DS_READ2_B32>(n_cu, clk); run<DS_READ2ST64>(n_cu, clk); run<DS_READ_B64>(n_cu, clk); run<DS_READ_B128>(n_cu, clk);
     run<DS_ADD_U32>(n_cu, clk); run<DS_ADD_U64>(n_cu, clk); run<DS_ADD_F32>(n_cu, clk); run<DS_WRITE_B32>(n_cu, clk);
+    run<DS_ADD_F32_ZERO>(n_cu, clk); run<DS_ADD_F32_HALF>(n_cu, clk); run<DS_ADD_RTN_F32>(n_cu, clk); run<DS_MAX_F32>(n_cu, clk); run<DS_ADD_F64>(n_cu, clk);
     return 0;
 }
