@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--no-shard-update", action="store_true",
                     help="sharded solver: all-reduce every slab and update the whole replica on every rank (round 3) instead of reduce-scatter -> "
                          "update of the rank's own 1/P -> all-gather")
+    ap.add_argument("--only-align", choices=["near", "start", "dense"], default=None,
+                    help="run ONLY that population of the alignment-gradient side measurement (config 5) and print its block: what the PMC passes of "
+                         "tools/profile_round.sh profile (the last dispatch of each gradient kernel is then the timed one)")
     ap.add_argument("--fwd-variant", type=int, default=None)
     ap.add_argument("--adj-variant", type=int, default=None)
     args = ap.parse_args()
@@ -179,6 +182,16 @@ def main():
         ctx.set_option("fwd_variant", args.fwd_variant)
     if args.adj_variant is not None:
         ctx.set_option("adj_variant", args.adj_variant)
+
+    if args.only_align:
+        out = {"alignment_gradient": align_rate(comm, ctx, rank, world, N=min(512, max(32, N // 2)), n_proj=720 if N >= 1024 else max(8, n_proj // 2),
+                                                legs=(args.only_align,))}
+        if rank == 0:
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        if world > 1 or args.force_sharded:
+            comm.close()
+        return
 
     geo = Geometry(n_proj, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
     phi = np.linspace(0., np.pi, n_proj)
@@ -531,10 +544,12 @@ def make_roofline(name, ms_per_step, launches_per_step, alg_bytes_per_pass, key,
     return r
 
 
-def align_rate(comm, ctx, rank, world, N=512, n_proj=720, passes=3):
+def align_rate(comm, ctx, rank, world, N=512, n_proj=720, passes=3, legs=("near", "start", "dense")):
     """Side measurement (not `value`): alignment cost+gradient evaluations per second on BASELINE config 5 -- 512^3
     volume, 720 projections with +-2 deg / +-5 px perturbations (default_rng(5)); projections are sharded over the
-    ranks with a replicated volume and no collective; one fused launch evaluates a rank's whole shard."""
+    ranks with a replicated volume and no collective; one fused launch evaluates a rank's whole shard.
+    Every population carries a `roofline` block: the gradient kernels' live launch times (HIP events) against the work the committed
+    PMC passes of the same command counted (profiles/sq_counters.json / pmc_traffic.json, workload keys C5_N<N>_P<n>_G<w>_<leg>)."""
     from tomography_alignment_amd import _lib
     from tomography_alignment_amd.backend import HipBackend
     from tomography_alignment_amd.utilities.geometry import Geometry
@@ -557,34 +572,108 @@ def align_rate(comm, ctx, rank, world, N=512, n_proj=720, passes=3):
     start = _lib.poses_array(phi[mine], 0 * alpha[mine], 0 * beta[mine], 0 * xyz[mine], np.zeros(3))
     alg = 4.0 * N ** 3 + 4.0 * N * N + 28.0                      # fused form, BASELINE.md section 3
 
-    def rate(poses, volume):
+    def rate(poses, volume, leg):
         be.cost_grad(poses, volume, b)
         ctx.sync()
         comm.barrier()
+        ctx.profile_reset()
+        ctx.profile_enable(True)
         t0 = time.perf_counter()
         for _ in range(passes):
             cost, g6 = be.cost_grad(poses, volume, b)
         ctx.sync()
         comm.barrier()
         dt = comm.allreduce_max(time.perf_counter() - t0)
-        return passes * n_proj / dt, float(cost[0])
+        ctx.profile_enable(False)
+        # the launches of one pass (one per kernel variant in use: poses are grouped by tilt), priced together
+        per = {}
+        for v in ("k_cost_grad(v1)", "k_cost_grad(v2)", "k_cost_grad(v3)"):
+            n, ms = ctx.profile_get(v)
+            if n:
+                per[v] = {"launches_per_pass": n / float(passes), "ms_per_pass": round(ms / passes, 3)}
+        roof = grad_roofline(per, mine.size * alg, "C5_N%d_P%d_G%d_%s" % (N, n_proj, world, leg), mine.size * float(N) ** 3)
+        return passes * n_proj / dt, float(cost[0]), per, roof
 
-    r_near, c_near = rate(near, vol)
-    r_start, c_start = rate(start, vol)
-    out = {"evals_per_sec": round(r_near, 1), "unit": "evals/s", "config": "%d^3 volume, %d projections simulated with +-2 deg / +-5 px pose "
-           "errors, fused cost+6-DoF gradient evaluated 0.5 deg / 1 px away from the true poses" % (N, n_proj),
-           "alg_GBps": round(r_near * alg / 1e9, 1), "frac_of_hbm_peak": round(r_near * alg / 1e9 / HBM_PEAK_GBS, 4),
-           "evals_per_sec_at_untilted_start": round(r_start, 1),
-           "projections_per_launch": int(mine.size), "cost_first": c_near, "cost_first_at_start": c_start}
-    # the same evaluation on a volume without zero voxels (the gradient kernels clip every ray to the bounding box of the
-    # non-zero voxels; Shepp-Logan fills about half of its cube)
-    dense = be.empty(N ** 3)
-    be.fill(dense, 0.05)
-    be.axpy(dense, vol, 1.0)
-    r_dense, _ = rate(near, dense)
-    out["dense_volume"] = {"evals_per_sec": round(r_dense, 1), "frac_of_hbm_peak": round(r_dense * alg / 1e9 / HBM_PEAK_GBS, 4),
-                           "config": "same poses and measured projections, volume = Shepp-Logan + 0.05 (no zero voxel)"}
+    out = {"unit": "evals/s", "projections_per_launch": int(mine.size)}
+    if "near" in legs:
+        r_near, c_near, per, roof = rate(near, vol, "near")
+        out.update({"evals_per_sec": round(r_near, 1), "config": "%d^3 volume, %d projections simulated with +-2 deg / +-5 px pose "
+                    "errors, fused cost+6-DoF gradient evaluated 0.5 deg / 1 px away from the true poses" % (N, n_proj),
+                    "alg_GBps": round(r_near * alg / 1e9, 1), "frac_of_hbm_peak": round(r_near * alg / 1e9 / HBM_PEAK_GBS, 4),
+                    "cost_first": c_near, "kernels": per, "roofline": roof})
+    if "start" in legs:
+        r_start, c_start, per, roof = rate(start, vol, "start")
+        out.update({"evals_per_sec_at_untilted_start": round(r_start, 1), "cost_first_at_start": c_start,
+                    "untilted_start": {"evals_per_sec": round(r_start, 1), "kernels": per, "roofline": roof}})
+    if "dense" in legs:
+        # the same evaluation on a volume without zero voxels (the gradient kernels clip every ray to the bounding box of the
+        # non-zero voxels; Shepp-Logan fills about half of its cube)
+        dense = be.empty(N ** 3)
+        be.fill(dense, 0.05)
+        be.axpy(dense, vol, 1.0)
+        r_dense, _, per, roof = rate(near, dense, "dense")
+        out["dense_volume"] = {"evals_per_sec": round(r_dense, 1), "frac_of_hbm_peak": round(r_dense * alg / 1e9 / HBM_PEAK_GBS, 4),
+                               "config": "same poses and measured projections, volume = Shepp-Logan + 0.05 (no zero voxel)", "kernels": per, "roofline": roof}
     return out
+
+
+def grad_roofline(per, alg_bytes_per_pass, key, samples_per_pass):
+    """The gradient kernels of one evaluation pass as ONE unit of work (a pass is one launch per variant in use): summed live time against
+    the summed counters of those launches.  Units: HBM (FETCH/WRITE counters), VALU busy, SALU issue (one scalar instruction per clock per
+    CU), TA busy (the texture-address path the gathers go through; profiles/round3_grad_counters.md) -- `bound` = the busiest."""
+    if not per:
+        return None
+    t = sum(v["ms_per_pass"] for v in per.values()) * 1e-3
+    alg_gbs = alg_bytes_per_pass / t / 1e9
+    r = {"kernels": sorted(per), "ms_per_pass": round(t * 1e3, 3), "hbm_algorithmic_frac": round(alg_gbs / HBM_PEAK_GBS, 4), "hbm_counter_frac": None,
+         "traffic": None, "counters": None,
+         "useful_flop_frac": round(30.0 * samples_per_pass / t / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4),
+         "useful_flop_note": "30 flop per in-volume sample: value 7 lerps x 2 + three gradient components (4 differences + 3 lerps x 2 each, shared partly): "
+                             "a count of the trilinear value + gradient arithmetic, not of the instructions spent"}
+    stale, sq, pmc, srcs = [], {}, 0.0, []
+    have_sq = have_pmc = True
+    for name in per:
+        ent, src = load_counters("sq_counters.json", key, name, stale)
+        if ent is None:
+            have_sq = False
+        else:
+            srcs.append(src)
+            for k, v in ent.items():
+                if isinstance(v, (int, float)):
+                    sq[k] = sq.get(k, 0.0) + v
+        ent, src = load_counters("pmc_traffic.json", key, name, stale)
+        if ent is None:
+            have_pmc = False
+        else:
+            pmc += ent["hbm_bytes_per_launch"]
+    if stale:
+        r["stale_counters_refused"] = sorted(set(stale))
+    util = {}
+    if have_pmc and pmc > 0:
+        r["traffic"] = pmc
+        r["hbm_counter_frac"] = round(pmc / t / 1e9 / HBM_PEAK_GBS, 4)
+        util["hbm"] = (pmc / t / 1e9, HBM_PEAK_GBS, "GB/s")
+    if have_sq and sq:
+        r["counters"] = {"source": srcs[0] if srcs else None, "per_pass": sq}
+        if sq.get("SQ_ACTIVE_INST_VALU"):
+            util["valu"] = (4.0 * sq["SQ_ACTIVE_INST_VALU"] / t / 1e9, N_CU * 4 * CLK_GHZ, "G SIMD-cycles/s")
+        if sq.get("SQ_INSTS_SALU"):
+            util["salu"] = (sq["SQ_INSTS_SALU"] / t / 1e9, N_CU * CLK_GHZ, "G scalar instr/s (one per clock per CU)")
+        if sq.get("TA_TA_BUSY_sum"):
+            util["ta"] = (sq["TA_TA_BUSY_sum"] / t / 1e9, N_CU * CLK_GHZ, "G TA-busy cycles/s (one TA per CU)")
+        if sq.get("SQ_INSTS_VALU"):
+            r["valu_instr_per_sample_wave"] = round(sq["SQ_INSTS_VALU"] / (samples_per_pass / 64.0), 2)
+        if sq.get("SQ_INSTS_VMEM_RD"):
+            r["vmem_loads_per_sample_wave"] = round(sq["SQ_INSTS_VMEM_RD"] / (samples_per_pass / 64.0), 2)
+    if not util:
+        r.update({"bound": "hbm", "achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 4),
+                  "note": "no committed PMC counters for workload key %s on these kernel sources: algorithmic-HBM figure" % key})
+        return r
+    bound = max(util, key=lambda k: util[k][0] / util[k][1])
+    ach, peak, unit = util[bound]
+    r.update({"bound": bound, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": unit, "frac": round(ach / peak, 4),
+              "utilisation": {k: {"achieved": round(v[0], 1), "peak": round(v[1], 1), "unit": v[2], "frac": round(v[0] / v[1], 4)} for k, v in util.items()}})
+    return r
 
 
 def align_rigid_e2e(comm, ctx, rank, world, sharded, N=512, n_proj=720, sirt_iters=10, n_outer=2):

@@ -377,9 +377,14 @@ extern "C" int tomo_profile_get(tomo_ctx *ctx, const char *kernel, int64_t *n, d
 {
     if (!ctx || !kernel) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
     prof_drain(ctx);
-    auto it = ctx->prof.find(kernel);
-    if (n) *n = it == ctx->prof.end() ? 0 : it->second.n;
-    if (ms) *ms = it == ctx->prof.end() ? 0.0 : it->second.ms;
+    // exact name, plus every record named `kernel(...)`: "k_cost_grad" sums its variants "k_cost_grad(v2)", "k_cost_grad(v3)"
+    int64_t cnt = 0;
+    double tot = 0.0;
+    const std::string base(kernel), pre = base + "(";
+    for (const auto &kv : ctx->prof)
+        if (kv.first == base || kv.first.compare(0, pre.size(), pre) == 0) { cnt += kv.second.n; tot += kv.second.ms; }
+    if (n) *n = cnt;
+    if (ms) *ms = tot;
     return TOMO_OK;
 }
 

@@ -608,13 +608,13 @@ extern "C" int tomo_cost_grad_rows(tomo_ctx *ctx, const double *h_poses, int n, 
         const ProjC *pc = d_pc + first;
         const GradC *gc = d_gc + first;
         if (variant == 1)
-            TOMO_LAUNCH(ctx, "k_cost_grad", k_proj_grad<true>, ray_grid(g, cnt), dim3(256), 0, pc, gc, ctx->d_volpad, (float *)nullptr,
+            TOMO_LAUNCH(ctx, "k_cost_grad(v1)", k_proj_grad<true>, ray_grid(g, cnt), dim3(256), 0, pc, gc, ctx->d_volpad, (float *)nullptr,
                         (float *)nullptr, d_b, d_resid, ctx->d_red, g, 0);
         else if (variant == 2)
-            TOMO_LAUNCH(ctx, "k_cost_grad", k_proj_grad_v2<true>, grad_grid(g, cnt), dim3(256), 0, pc, gc, ctx->d_volpad, (float *)nullptr,
+            TOMO_LAUNCH(ctx, "k_cost_grad(v2)", k_proj_grad_v2<true>, grad_grid(g, cnt), dim3(256), 0, pc, gc, ctx->d_volpad, (float *)nullptr,
                         (float *)nullptr, d_b, d_resid, ctx->d_red, g, grad_zslow(g, cnt) ? 16 : 0);
         else
-            TOMO_LAUNCH(ctx, "k_cost_grad", k_proj_grad_v3<true>, grad_grid(g, cnt), dim3(256), 0, pc, gc, ctx->d_volpad, (float *)nullptr,
+            TOMO_LAUNCH(ctx, "k_cost_grad(v3)", k_proj_grad_v3<true>, grad_grid(g, cnt), dim3(256), 0, pc, gc, ctx->d_volpad, (float *)nullptr,
                         (float *)nullptr, d_b, d_resid, ctx->d_red, g, grad_zslow(g, cnt) ? 16 : 0);
     }
     TOMO_HIP(ctx, hipMemcpyAsync(ctx->h_red, ctx->d_red, sizeof(double) * (size_t)n * 7, hipMemcpyDeviceToHost, ctx->stream));

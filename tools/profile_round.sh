@@ -1,8 +1,9 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag> [legs]      legs: subset of "H D P" (default "H D P")
+# usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag> [legs]      legs: subset of "H D P G" (default "H D P G")
 #   H  the headline workload            bench.py                    key N1024_A1024_G1
 #   D  its dense-volume leg             bench.py --dense            key N1024_A1024_G1_D   (Shepp-Logan + 0.05: no zero voxel, nothing skipped)
 #   P  its tilted-pose leg              bench.py --perturbed        key N1024_A1024_G1_P   (general tile kernels)
+#   G  the alignment-gradient kernels   bench.py --only-align near|dense   keys C5_N512_P720_G1_near / _dense  (config 5: k_cost_grad(v2|v3); + a TA pass)
 # 1. rocprofv3 --kernel-trace --stats of the default bench.py run (all legs in one process: the per-dispatch durations of every kernel)
 # per leg: 2./3. separate --pmc FETCH_SIZE / WRITE_SIZE passes and 4./5. two --pmc SQ passes of `bench.py --steps 1 --warmup 1 <leg>`
 #    (the last dispatch of each kernel is the timed step)
@@ -10,7 +11,7 @@
 # files hold all legs, keyed by workload, and the kernel-source hash they were taken on).
 # Every rocprofv3 run has the program itself after `--` (no shell / env hop), counters never combined with tracing.
 tag=$1
-legs=${2:-"H D P"}
+legs=${2:-"H D P G"}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 SIDE="--steps 1 --warmup 1 --no-align --no-tilted --no-dense --no-cpu-baseline"
 OUT=gpurun_out/${tag}_profiles
@@ -19,7 +20,25 @@ timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpu
 echo "stats pass done"
 SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
 SQ2="SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_BUSY_CYCLES"
+TA="TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"
 for leg in $legs; do
+    if [ "$leg" = "G" ]; then
+        for sub in near dense; do
+            t=${tag}_G${sub}
+            for pass in fetch write sq1 sq2 ta; do
+                case $pass in
+                    fetch) ctrs="FETCH_SIZE";; write) ctrs="WRITE_SIZE";; sq1) ctrs="$SQ1";; sq2) ctrs="$SQ2";; ta) ctrs="$TA";;
+                esac
+                cd /tmp
+                timeout -k 10 400 rocprofv3 --pmc $ctrs --output-format csv -d $R/gpurun_out/${t}_${pass} -o run -- python3 $R/bench.py --only-align $sub > $R/gpurun_out/${t}_${pass}.json 2> $R/gpurun_out/${t}_${pass}.err || { echo "gradient $sub: $pass pass failed"; tail -5 $R/gpurun_out/${t}_${pass}.err; exit 1; }
+                echo "gradient $sub: $pass pass done"
+            done
+            cd $R
+            python3 tools/summarise_rocprof.py $t gpurun_out/${tag}_stats gpurun_out/${t}_fetch gpurun_out/${t}_write --which last --workload "config 5: 512^3 x 720 poses, alignment gradient, $sub (stats: bench.py default; PMC passes: bench.py --only-align $sub, last dispatch of each kernel)" --key C5_N512_P720_G1_$sub --out $OUT > /dev/null
+            python3 tools/summarise_sq.py $t C5_N512_P720_G1_$sub gpurun_out/${t}_sq1 gpurun_out/${t}_sq2 gpurun_out/${t}_ta --workload "bench.py --only-align $sub" --out $OUT > /dev/null
+        done
+        continue
+    fi
     case $leg in
         H) flag=""; sfx=""; what="headline";;
         D) flag="--dense"; sfx="_D"; what="dense volume";;
