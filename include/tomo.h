@@ -270,7 +270,8 @@ TOMO_API int tomo_release_workspace(tomo_ctx *ctx);
  * when EVERY entry is masked the reference keeps them all with weight 0, :63-65 -- so does this), COO -> CSR with duplicates summed,
  * explicit zeros kept, column indices sorted.  tomo_csr_assemble builds the matrix in device memory held by the context and returns its
  * number of stored entries; tomo_csr_fetch copies data (float32 or float64 by precision_bits) / indices (int32) / indptr (int64,
- * n_proj * n_det + 1) into the caller's host arrays and frees the device copy.  Small volumes only (the reference's matrix at
+ * n_proj * n_det + 1) into the caller's host arrays and frees the device copy; with all three pointers NULL it only frees it (a
+ * caller that finds the matrix larger than it is willing to download).  Small volumes only (the reference's matrix at
  * 128^3 x 64 is 4.5 GB); TOMO_ERR_UNSUPPORTED beyond int32 indices or 2^31 triplets. */
 TOMO_API int tomo_csr_assemble(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_mask, int precision_bits, int64_t *h_nnz);
 TOMO_API int tomo_csr_fetch(tomo_ctx *ctx, void *h_data, int32_t *h_indices, int64_t *h_indptr);

@@ -372,12 +372,21 @@ def test_flat_forward_kernel_variants(PM, orc, shape, ndet, step):
     for tab in (0, 1):
         ctx.set_option("fwd_flat_tab", tab)
         res[tab] = A.dot(x.ravel())
-    ctx.set_option("fwd_flat_wide", 1)
-    f_wide = A.dot(x.ravel())
-    ctx.set_option("fwd_flat_wide", 0)
+    # the 32 x 16-footprint variant exists only in measurement builds (make EXTRA=-DTOMO_MEASUREMENT_VARIANTS, round 5): the product library
+    # refuses the option by name
+    from tomography_alignment_amd import _lib
+    n_variants = 2
+    try:
+        ctx.set_option("fwd_flat_wide", 1)
+        f_wide = A.dot(x.ravel())
+        ctx.set_option("fwd_flat_wide", 0)
+        n_variants = 3
+    except _lib.TomoError as e:
+        assert "measurement variant" in str(e)
+        f_wide = res[1]
     ctx.set_option("fwd_flat_tab", TAB_DEFAULT)
     ctx.profile_enable(False)
-    assert ctx.profile_get("k_fwd_tile_flat")[0] == 3 and ctx.profile_get("k_fwd_tile")[0] == 0
+    assert ctx.profile_get("k_fwd_tile_flat")[0] == n_variants and ctx.profile_get("k_fwd_tile")[0] == 0
     assert rel_max(res[0], want) < TOL and rel_max(res[1], want) < TOL and rel_max(f_wide, want) < TOL
     assert rel_max(res[1], res[0]) < 2e-6 and rel_max(f_wide, res[0]) < 2e-6
     # all-zero images beside non-zero ones (the kernels skip them): the ray between two images / two work-groups of the round-3 kernel
@@ -885,6 +894,15 @@ def test_csr_assembled_on_the_device_equals_host_assembly(PM, capsys):
                 assert D.nnz > 0 and not D.data.any()                      # every entry kept, all weights zero
             T = A.T.tocsr()
             assert T.shape == (D.shape[1], D.shape[0]) and abs(T.sum() - D.sum()) <= 1e-5 * abs(D.sum()) + 1e-12
+    # max_nnz is enforced BEFORE anything is allocated on the host or downloaded, the device copy is dropped on refusal
+    # (a second fetch finds nothing), and the operator assembles again afterwards
+    from tomography_alignment_amd import _lib
+    with pytest.raises(MemoryError):
+        A.tocsr(max_nnz=D.nnz - 1)
+    be_ = A.backend
+    with pytest.raises(_lib.TomoError, match="nothing assembled"):
+        be_.ctx.check(be_.lib.tomo_csr_fetch(be_.ctx.handle, None, None, np.zeros(4, np.int64).ctypes.data_as(_lib._c_vp)))
+    assert A.tocsr(max_nnz=D.nnz).nnz == D.nnz
     # what it buys: 64^3 x 8 (the reference itself: 35 s for 90 angles at this size)
     geo64, _ = geo_pair(8, 64)
     A = PM(geo64).projection_matrix()

@@ -140,18 +140,26 @@ class HipBackend(object):
                                                         _lib.dptr(cost), _lib.dptr(g6), resid.ptr if resid is not None else None))
         return cost, g6
 
-    def csr_assemble(self, poses, mask=None, precision=np.float32):
+    def csr_assemble(self, poses, mask=None, precision=np.float32, max_nnz=None):
         """The reference's assembled projection matrix (utilities/projection_operators.py:54-76) built on the device: triplets of all
-        projections, mask filter, sort, duplicate sums, row pointers -> (data [precision], indices int32, indptr int64)."""
+        projections, mask filter, sort, duplicate sums, row pointers -> (data [precision], indices int32, indptr int64).
+        max_nnz: refuse (MemoryError) BEFORE any host array is allocated or a byte is downloaded; the device copy is dropped on refusal
+        and on any failure between assembly and download."""
         self._geom()
         bits = 64 if np.dtype(precision) == np.float64 else 32
         nnz = ctypes.c_int64(0)
         poses = np.ascontiguousarray(poses, np.float64)
         self.ctx.check(self.lib.tomo_csr_assemble(self.ctx.handle, _lib.dptr(poses), poses.shape[0], mask.ptr if mask is not None else None, bits,
                                                   ctypes.byref(nnz)))
-        data = np.empty(nnz.value, np.float64 if bits == 64 else np.float32)
-        indices = np.empty(nnz.value, np.int32)
-        indptr = np.empty(poses.shape[0] * self.n_det + 1, np.int64)
+        try:
+            if max_nnz is not None and nnz.value > max_nnz:
+                raise MemoryError("tocsr: %d entries, more than %d; keep the operator matrix-free" % (nnz.value, max_nnz))
+            data = np.empty(nnz.value, np.float64 if bits == 64 else np.float32)
+            indices = np.empty(nnz.value, np.int32)
+            indptr = np.empty(poses.shape[0] * self.n_det + 1, np.int64)
+        except BaseException:
+            self.lib.tomo_csr_fetch(self.ctx.handle, None, None, None)      # drop the device copy (tens of GB at 128^3)
+            raise
         self.ctx.check(self.lib.tomo_csr_fetch(self.ctx.handle, data.ctypes.data_as(_c_vp), indices.ctypes.data_as(_c_vp), indptr.ctypes.data_as(_c_vp)))
         return data, indices, indptr
 

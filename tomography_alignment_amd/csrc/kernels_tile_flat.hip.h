@@ -523,9 +523,6 @@ __global__ __launch_bounds__(1024) void k_fwd_compact(const unsigned char *__res
     if (threadIdx.x == 0) list[0] = base;
 }
 
-#ifndef TOMO_FWD_TAB_W
-#define TOMO_FWD_TAB_W 1         // where an entry's weights come from: 1 = the wave's LDS table (shipped); 0 / 2 = measurement variants (see the loop)
-#endif
 #define FT2_TAB 32
 #define FT2_TAB_ALLOC (FT2_TAB + 4)      // a wave's table: the owners' entries of one pass (<= FT2_TAB) + padding to a 64-B multiple
 __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
@@ -627,11 +624,7 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
                     const int n_own = (int)__builtin_popcountll(om);
                     const int first = (int)__builtin_ctzll(om);
                     const unsigned slot = (unsigned)(lane - first);
-#if TOMO_FWD_TAB_W == 1
                     if (slot < (unsigned)n_own) tw[slot] = make_float4(t_w00, t_w01, t_w10, t_w11);      // owners only: no padding entries (see the loops)
-#elif TOMO_FWD_TAB_W == 2
-                    if (slot < (unsigned)n_own) ((float2 *)tw)[slot] = make_float2(t_w10, t_w11);
-#endif
                     // The cell ADDRESS of an entry is broadcast with one v_readlane (lanes that own nothing carry address 0), the four weights come
                     // from the wave's LDS table (broadcast ds_read_b128): the data reads of a group do not wait for an LDS round trip of the table
                     // -- they are issued beside the weight reads, which are needed only at the FMAs.  4 + 8 LDS clk per entry.
@@ -654,7 +647,8 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
                             /* copies W.w to a fresh register first: one v_mov per entry)                                          */ \
                             FT2_FMAS(J, W)                                                                                  \
                         }
-#if TOMO_FWD_TAB_W == 1
+                    // (round 3 also measured the weights broadcast with v_readlane instead of read from the table, wholly or by halves:
+                    //  slower, profiles/round3_fwd_tab_variants.md, profiles/round3_fwd_weight_source_ab.log -- those variants are in git history only)
 #define FT2_FMAS(J, W)                                                                                                     \
                             const f32x2 w01_ = {(W).x, (W).y}, w23_ = {(W).z, (W).w};                                       \
                             asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(Pa) : "v"(w01_), "v"(v00));          \
@@ -663,24 +657,6 @@ __global__ __launch_bounds__(FZ_WAVES * 64) void k_fwd_flat_tab(const AdjC *__re
                             asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(Pb) : "v"(w23_), "v"(v11));
 #define FT2_W(J) tw[j4 + (J)]
                     typedef float4 ft2_w_t;
-#elif TOMO_FWD_TAB_W == 2      /* measurement variant: w00, w01 by v_readlane, w10, w11 from the table (ds_read_b64) */
-#define FT2_FMAS(J, W)                                                                                                     \
-                            const f32x2 w23_ = {(W).x, (W).y};                                                              \
-                            Pa += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_w00), first + j4 + (J))) * v00; \
-                            Pb += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_w01), first + j4 + (J))) * v01; \
-                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(Pa) : "v"(w23_), "v"(v10));          \
-                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(Pb) : "v"(w23_), "v"(v11));
-#define FT2_W(J) ((const float2 *)tw)[j4 + (J)]
-                    typedef float2 ft2_w_t;
-#else                          /* measurement variant: all four weights by v_readlane, no table */
-#define FT2_FMAS(J, W)                                                                                                     \
-                            Pa += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_w00), first + j4 + (J))) * v00; \
-                            Pb += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_w01), first + j4 + (J))) * v01; \
-                            Pa += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_w10), first + j4 + (J))) * v10; \
-                            Pb += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_w11), first + j4 + (J))) * v11;
-#define FT2_W(J) 0
-                    typedef int ft2_w_t;
-#endif
                     int j4 = 0;
                     for (; j4 + 4 <= n_own; j4 += 4) {                                         // wave-uniform; four entries in flight, no padding
                         const ft2_w_t wa = FT2_W(0), wb = FT2_W(1), wc = FT2_W(2), wd = FT2_W(3);

@@ -209,7 +209,14 @@ extern "C" int tomo_csr_assemble(tomo_ctx *ctx, const double *h_poses, int n_pro
 
 extern "C" int tomo_csr_fetch(tomo_ctx *ctx, void *h_data, int32_t *h_indices, int64_t *h_indptr)
 {
-    if (!ctx || !h_indptr) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_csr_fetch: bad args");
+    if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_csr_fetch: null ctx");
+    if (!h_data && !h_indices && !h_indptr) {      // discard: the caller decided against the download (max_nnz is checked BEFORE host arrays exist)
+        TOMO_HIP(ctx, hipSetDevice(ctx->device));
+        TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        csr_release(ctx);
+        return TOMO_OK;
+    }
+    if (!h_indptr) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_csr_fetch: bad args");
     if (!ctx->csr_indptr) return tomo_fail(ctx, TOMO_ERR_STATE, "tomo_csr_fetch: nothing assembled");
     TOMO_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->csr_nnz > 0) {

@@ -81,7 +81,7 @@ struct tomo_ctx {
     int tile_flat = 1;      // 1: untilted projections take the flat tile kernels
     int adj_flat_gather = 1;  // 1: untilted unit lattices take the gather-form adjoint (k_adj_gather_flat) instead of the LDS-atomic flat kernel
     int fwd_flat_tab = 1;     // 1 (default): the flat forward with the sample table in LDS and the two images interleaved per plane (k_fwd_flat_tab); 0: the round-2 kernel (k_fwd_flat_z<2>: entries broadcast with v_readlane)
-    int fwd_flat_wide = 0;    // 1: measurement variant of the flat forward -- 32 x 16 x 63 footprint, one image per work-group (k_fwd_flat_z<1, 32>)
+    int fwd_flat_wide = 0;    // 1: measurement variant of the flat forward -- 32 x 16 x 63 footprint, one image per work-group (k_fwd_flat_z<1, 32>); only in builds with -DTOMO_MEASUREMENT_VARIANTS
     int fwd_flat_ztiles = 2;  // 2: the flat forward processes two z-adjacent tiles per work-group (k_fwd_flat_z<2>); 1: one tile (k_tile_flat<true>)
     // timing / profiling
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -124,7 +124,10 @@ void tomo_prof_end_on(tomo_ctx *ctx, hipStream_t stream);
     do {                                                                                 \
         if (!(ctx)) return tomo_fail(nullptr, TOMO_ERR_ARG, "null ctx");                 \
         if (!(ctx)->has_geom) return tomo_fail((ctx), TOMO_ERR_STATE, "geometry not set"); \
-        (void)hipSetDevice((ctx)->device);   /* the current device is per THREAD: a caller's helper thread starts on device 0 */ \
+        {   /* the current device is per THREAD: a caller's helper thread starts on device 0 */                     \
+            hipError_t e_ = hipSetDevice((ctx)->device);                                                         \
+            if (e_ != hipSuccess) return tomo_fail((ctx), TOMO_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e_)); \
+        }                                                                                                        \
     } while (0)
 
 // launch with optional event bracketing (tomo_profile_enable) and launch-error check

@@ -161,7 +161,13 @@ extern "C" int tomo_set_option(tomo_ctx *ctx, const char *key, int value)
     else if (!strcmp(key, "comm_test_poison_us")) ctx->comm_test_poison_us = value;
     else if (!strcmp(key, "adj_flat_gather")) ctx->adj_flat_gather = value;
     else if (!strcmp(key, "fwd_flat_ztiles")) ctx->fwd_flat_ztiles = value;
-    else if (!strcmp(key, "fwd_flat_wide")) ctx->fwd_flat_wide = value;
+    else if (!strcmp(key, "fwd_flat_wide")) {
+#ifdef TOMO_MEASUREMENT_VARIANTS
+        ctx->fwd_flat_wide = value;
+#else
+        if (value) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "fwd_flat_wide is a measurement variant: build with EXTRA=-DTOMO_MEASUREMENT_VARIANTS (csrc/Makefile)");
+#endif
+    }
     else if (!strcmp(key, "fwd_flat_tab")) ctx->fwd_flat_tab = value;
     else if (!strcmp(key, "reuse_staged_volume")) ctx->reuse_staged = value;
     else if (!strcmp(key, "reuse_sino_flags")) ctx->reuse_sino_flags = value;

@@ -247,10 +247,13 @@ static int forward_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
     if (n_flat > 0) {
         dim3 fg = tile_grid(g, FTZ);
         fg.z = grid.z;
+#ifdef TOMO_MEASUREMENT_VARIANTS
         if (ctx->fwd_flat_wide && xt0 == 0 && xt1 == (int)tile_grid(g).z)    // measurement variant: 32 x 16 footprint, one image (whole-volume calls only)
             TOMO_LAUNCH(ctx, "k_fwd_tile_flat", (k_fwd_flat_z<1, 32>), dim3(fg.x, fg.y, (g.nx + 1 + 31) / 32), dim3(FZ_WAVES * 64), 0, d_c, n_flat,
                         d_proj, d_vol, g, 0);
-        else if (fg.x >= 2 && ctx->fwd_flat_ztiles >= 2 && ctx->fwd_flat_tab) {    // round 3: LDS sample table + image pairs, live blocks only
+        else
+#endif
+        if (fg.x >= 2 && ctx->fwd_flat_ztiles >= 2 && ctx->fwd_flat_tab) {    // round 3: LDS sample table + image pairs, live blocks only
             const int nzb = (g.nz + 2 * FLZ - 1) / (2 * FLZ), nty = (int)fg.y;
             const size_t n_blk = (size_t)nzb * nty * fg.z;
             if (n_blk >= (size_t)1 << 30) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_forward: volume too large for the flat forward's block list");

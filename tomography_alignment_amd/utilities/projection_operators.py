@@ -155,9 +155,7 @@ class RayOperator(object):
         if device and hasattr(be, "csr_assemble") and np.dtype(f.precision) in (np.dtype(np.float32), np.dtype(np.float64)):
             # round 4: everything on the device -- triplets of all projections, mask, sort, duplicate sums, row pointers (csrc/tomo_csr.hip);
             # the host only receives the finished arrays
-            data, indices, indptr = be.csr_assemble(f.poses, f._mask, f.precision)
-            if data.size > max_nnz:
-                raise MemoryError("tocsr: more than %d entries; keep the operator matrix-free" % max_nnz)
+            data, indices, indptr = be.csr_assemble(f.poses, f._mask, f.precision, max_nnz=max_nnz)      # refuses before anything is downloaded
             idx = np.int32 if max(data.size, f.shape[1]) < 2 ** 31 - 1 else np.int64        # what scipy picks for a matrix of this size
             A = sparse.csr_matrix((data, indices.astype(idx, copy=False), indptr.astype(idx, copy=False)), shape=f.shape)
             return A.T.tocsr() if self._is_adjoint else A
