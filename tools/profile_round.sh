@@ -16,8 +16,13 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 SIDE="--steps 1 --warmup 1 --no-align --no-tilted --no-dense --no-cpu-baseline"
 OUT=gpurun_out/${tag}_profiles
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -o run -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${tag}_bench_under_rocprof.json 2> $R/gpurun_out/${tag}_stats.err || { echo "stats pass failed"; tail -5 $R/gpurun_out/${tag}_stats.err; exit 1; }
-echo "stats pass done"
+# counters of an earlier call of the same round (same kernel sources) are carried along: a round's passes do not fit one 20-minute GPU call
+mkdir -p $R/$OUT
+for f in sq_counters.json pmc_traffic.json; do [ -f $R/profiles/$f ] && cp $R/profiles/$f $R/$OUT/$f; done
+if [ -z "$SKIP_STATS" ]; then
+    timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -o run -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${tag}_bench_under_rocprof.json 2> $R/gpurun_out/${tag}_stats.err || { echo "stats pass failed"; tail -5 $R/gpurun_out/${tag}_stats.err; exit 1; }
+    echo "stats pass done"
+fi
 SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
 SQ2="SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_BUSY_CYCLES"
 TA="TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"
@@ -59,6 +64,8 @@ for leg in $legs; do
     python3 tools/summarise_sq.py $t N1024_A1024_G1$sfx gpurun_out/${t}_sq1 gpurun_out/${t}_sq2 --workload "bench.py $SIDE $flag" --out $OUT > /dev/null
 done
 cd $R
-cp gpurun_out/${tag}_bench_under_rocprof.json $OUT/${tag}_bench_under_rocprof.json
-find gpurun_out/${tag}_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${tag}_kernel_stats.csv \;
+if [ -z "$SKIP_STATS" ]; then
+    cp gpurun_out/${tag}_bench_under_rocprof.json $OUT/${tag}_bench_under_rocprof.json
+    find gpurun_out/${tag}_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${tag}_kernel_stats.csv \;
+fi
 echo "summary done: $(ls $OUT)"

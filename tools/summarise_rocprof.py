@@ -83,7 +83,8 @@ def main():
                     help="which dispatch of a kernel the PMC table reports: the largest, or the last (= the timed step of a --steps 1 --warmup 1 run)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
-    rows = list(csv.DictReader(open(find(a.stats_dir, "*kernel_stats.csv"))))
+    stats_csv = find(a.stats_dir, "*kernel_stats.csv")
+    rows = list(csv.DictReader(open(stats_csv))) if stats_csv else []       # (a PMC-only call of a round has no stats pass of its own)
     fetch, write = pmc(a.fetch_dir, "FETCH_SIZE"), pmc(a.write_dir, "WRITE_SIZE")
     lines = ["# rocprofv3 summary `%s`" % a.tag, "", "workload: %s" % a.workload, "",
              "## `rocprofv3 --kernel-trace --stats -- python3 bench.py ...`", "",
