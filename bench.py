@@ -12,7 +12,7 @@ A "step" is one SIRT iteration: A.rec, residual, A^T(W*res), all-reduce of the v
 angle shards (RCCL over xGMI; strong scaling: the 1024 angles are split across the N GPUs), update.
 Inputs are resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
 
-Extra objects in the line ("Measurement"):
+Extra objects in the line:
   roofline     the projector kernel that takes most of a step: work counted per launch by unit (VALU execution cycles, LDS-array
                cycles, HBM bytes -- rocprofv3 PMC passes of THIS command, committed under profiles/) / mean launch time
                measured live (HIP events on the kernel's own stream inside the timed region) against what the chip offers
@@ -538,7 +538,7 @@ def make_roofline(name, ms_per_step, launches_per_step, alg_bytes_per_pass, key,
             info["lds_frac_of_peak_bandwidth"] = round(sq["lds_bytes"] / t / 1e9 / LDS_PEAK_GBS, 4)
         if sq.get("SQ_INSTS_SALU"):
             info["salu_Ginstr_per_s"] = round(sq["SQ_INSTS_SALU"] / t / 1e9, 1)
-            # one scalar unit per CU: the gather back-projection was limited by it at 0.6 of one instruction per clock
+            # one scalar unit per CU: the gather back-projection was limited by it at 0.6 of one instruction per clock (HISTORY.md section 4)
             info["salu_frac_of_one_per_clk_per_cu"] = round(sq["SQ_INSTS_SALU"] / t / 1e9 / (N_CU * CLK_GHZ), 4)
         r["instruction_rates"] = info
     return r

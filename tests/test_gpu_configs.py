@@ -110,7 +110,7 @@ def test_config5_projection_gradient_512_all_variants(c5, capsys):
     Value: all rays, 1e-5.  Gradient rows: 1e-5 of the row's maximum on every ray whose samples all keep >= 4e-6 voxel
     (conftest.FACE_TOL_KERNELS; 2e-5 until round 3) from a cell face -- across a face the interpolant's value is continuous but its spatial gradient jumps (by the local second
     difference: O(1) on the piecewise-constant phantom), so a sample within the kernels' float32 position rounding
-    (<= 1.3e-6 voxel, tools/grad_error_model.py) of a face may legitimately sit on the other side."""
+    (<= 1.3e-6 voxel, tools/grad_error_model.py) of a face may legitimately sit on the other side (HISTORY.md section 2)."""
     be, N, n_det = c5["be"], c5["N"], c5["N"] ** 2
     pr, gd = be.empty(n_det), be.empty(6 * n_det)
     rows, masked = [], []

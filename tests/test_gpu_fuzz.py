@@ -110,7 +110,7 @@ def test_gradient_kernels_agree_on_random_geometry(seed):
     rows shorter than a wave).  Per ray: every kernel (1 plain, 2 dword gathers, 3 neighbour shift, 4 per-pose dispatch) against the
     float64 oracle -- the value on all rays, the gradient on the rays whose samples keep >= 2e-5 voxel from a cell face (across a face the
     interpolant's gradient jumps, so a sample within the kernels' float32 position rounding of one flips sides: all four kernels then
-    agree with each other and differ from the oracle by that one sample) -- and kernels 3, 4 against kernel 2 on
+    agree with each other and differ from the oracle by that one sample; HISTORY.md section 2) -- and kernels 3, 4 against kernel 2 on
     all rays (same positions, lerps in another order).  Fused: cost and the six gradient sums against the sums of the kernel's own
     per-ray outputs (the reduction itself), and the cost against the oracle."""
     from oracle import oracle as orc
@@ -121,7 +121,7 @@ def test_gradient_kernels_agree_on_random_geometry(seed):
     worst_ray = worst_orc = worst_sum = 0.0
     for k in range(6):
         # Any shape, also longer in x than in y: there the rays (y = -ny .. +ny about the rotation centre, geometry.py:95-100) end inside
-        # the object and the last of the n = int(|r0| / step) samples counts -- the library must round |r0| as numpy does.
+        # the object and the last of the n = int(|r0| / step) samples counts -- the library must round |r0| as numpy does (HISTORY.md section 2).
         shape = tuple(int(v) for v in rng.integers(16, 72, 3))
         ndet = (int(rng.integers(5, 80)), int(rng.integers(3, 140)))
         step = float(rng.choice([1.0, 1.0, 0.5, 1.3]))
@@ -191,7 +191,7 @@ def test_gradient_kernels_agree_on_random_geometry(seed):
 
 
 def test_gradient_cancellation_regression_59x71x61_detector_21x5():
-    """Named regression (profiles/round4_grad_error_model.md): the one geometry on which the round-3 soak
+    """Named regression (HISTORY.md section 2, profiles/round4_grad_error_model.md): the one geometry on which the round-3 soak
     saw the gradient kernels leave 1e-5 of the float64 oracle (seed 81: 1.06e-5 / 1.19e-5 on the translation rows of pose 1, every
     variant alike).  Smooth 59 x 71 x 61 volume, 21 x 5 detector, phi ~ pi/2: the per-sample gradients of a ray cancel to 1e-4 of their
     sum of magnitudes along the beam and the translation rows' maximum over the 105 rays is 0.05 -- float32 rounding at the size of
@@ -252,7 +252,7 @@ def test_gradient_cancellation_regression_59x71x61_detector_21x5():
 
 
 def test_samples_per_ray_regression_54x18x27():
-    """Named regression (VERDICT r2 #4 / DESIGN.md section 2): n = int(|r0| / step) (utilities/ray_voxel_utilities.py:88).  On a volume
+    """Named regression (VERDICT r2 #4 / HISTORY.md section 2): n = int(|r0| / step) (utilities/ray_voxel_utilities.py:88).  On a volume
     longer in x than in y the last sample of an oblique ray lies INSIDE the object, so n = K - 1 against K changes projections by a
     whole sample.  Round 2's random-geometry test found this very case: 54 x 18 x 27, detector 34 x 90, and a pose for which numpy
     rounds |r0| to 35.99999999999999 (n = 35) where plain a*b + c*d + e*f products give 36.0.  Every forward kernel, the adjoint

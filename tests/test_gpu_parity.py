@@ -350,7 +350,7 @@ def test_untilted_poses_take_the_flat_tile_kernels(PM, orc, shape, ndet):
 def test_flat_forward_kernel_variants(PM, orc, shape, ndet, step):
     """The variants of the flat forward -- the round-2 kernel (entries broadcast with v_readlane, option fwd_flat_tab = 0), the round-3
     kernel (sample table in LDS, the two images interleaved per plane: fwd_flat_tab = 1) and the 32 x 16-footprint measurement variant
-    (fwd_flat_wide, DESIGN.md section 4 "forward write amplification") -- compute the same projections as each other and as the
+    (fwd_flat_wide, HISTORY.md section 4 "forward write amplification") -- compute the same projections as each other and as the
     oracle: volumes whose x extent is not a multiple of 32, exactly degenerate angles, translations, COR shifts, and steps below a
     voxel (rows with more samples in a tile than one pass of the table holds); z extents of one to three of the round-3 kernel's
     128-plane work-groups with fractional z translations (the ray between two work-groups receives a part from each)."""
@@ -538,7 +538,7 @@ def test_gradient_kernel_variants_agree_on_odd_shapes(PM, orc, shape, ndet):
 
 @pytest.mark.parametrize("case", ["lane63_only", "lane0_only", "short_row", "all_miss", "lane63_only_tilted", "one_row_tilted"])
 def test_gradient_kernels_idle_lane_addressing(PM, orc, case):
-    """Regression for the GPU abort of round 1: the first neighbour-lane-shift gradient kernel let lanes
+    """Regression for the GPU abort of round 1 (HISTORY.md section 8): the first neighbour-lane-shift gradient kernel let lanes
     OUTSIDE their own sample range [lo, hi) form gather addresses from their out-of-volume positions -- a wave-uniform sample
     loop with every lane loading -- and faulted as soon as such an address left mapped memory.  Today every lane loads either at
     a sample of its own range or at the borrowed address of a lane that has one.  The shapes here make that path the common

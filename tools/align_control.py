@@ -5,7 +5,7 @@ Control experiment for the joint reconstruction + alignment loop (VERDICT r2 "mi
 bounds +-3 px / +-0.02 rad) reduce the tilt error, or does it stall like this package's 512^3 run of round 1 (shift error falls,
 tilt error stays ~1 deg)?  Authoring container only: imports the reference's python + f2py modules (oracle/_ref, /root/reference)
 exactly as tests/golden/make_golden.py does, and runs the same data through this package's loop on the CPU stand-in backend
-(tests/backends.OracleBackend).  Development aid; its output is recorded in DESIGN.md.
+(tests/backends.OracleBackend).  Development aid; its output is recorded in HISTORY.md.
 
     python tools/align_control.py [N=32] [n_proj=24] [n_outer=4] [sirt_iters=30] [ang_deg=1.0] [shift_px=2.0] [bound_px=3] [bound_rad=0.02]
 """

@@ -1,5 +1,5 @@
 // tools/issue_bench.hip -- what one CU of an MI355X can issue per clock, measured: the denominators of bench.py's roofline
-// for the LDS-tile kernels (VALU wave-instructions, LDS wave-instructions) and the numbers behind DESIGN.md's cycle budgets.
+// for the LDS-tile kernels (VALU wave-instructions, LDS wave-instructions) and the numbers behind HISTORY.md's cycle budgets.
 //
 //   hipcc -O3 --offload-arch=gfx950 tools/issue_bench.hip -o /tmp/issue_bench && /tmp/issue_bench
 //

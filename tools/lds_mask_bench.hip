@@ -1,5 +1,5 @@
 // micro-benchmark (development aid, round 3): what does an LDS atomic / read cost when only SOME lanes of the wave are active?
-// Question behind it (tilted adjoint): schemes that merge the upper-plane contributions of lane l with the
+// Question behind it (HISTORY.md section 4, tilted adjoint): schemes that merge the upper-plane contributions of lane l with the
 // lower-plane ones of lane l+1 need a fallback pass for the few lanes whose neighbour sits in another cell.  That pass only pays if
 // a ds_add_u32 with 2-4 active lanes is cheaper than one with 64.
 // Every CU busy (1024 work-groups of 512 threads, 2 resident per CU), conflict-free addresses (lanes on consecutive dwords).

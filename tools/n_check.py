@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How often does the library's n = int(|r0| / step) differ from numpy's (the reference's)?  Development aid, CPU only:
 builds a small host program around csrc/tomo_raycore.h and compares it with oracle.ray_setup over random poses of a volume that
-is longer in x than in y (where the last sample of a ray lies inside the object)."""
+is longer in x than in y (where the last sample of a ray lies inside the object, HISTORY.md section 2)."""
 import os
 import subprocess
 import sys

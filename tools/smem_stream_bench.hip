@@ -1,5 +1,5 @@
 // micro-benchmark (development aid, round 3): how fast can the SCALAR data cache stream data that is read once?
-// Question behind it: the flat forward spends 5 of its 10 VALU instructions per sample entry on v_readlane
+// Question behind it (HISTORY.md section 7): the flat forward spends 5 of its 10 VALU instructions per sample entry on v_readlane
 // broadcasts of a per-row table; feeding that table through s_load_dwordx8 instead would free them -- but every entry is read
 // exactly once, i.e. every scalar load misses the scalar cache: ~3e10 entries/s x 32 B = ~1 TB/s chip-wide would be needed.
 // Each wave streams its own region with s_load_dwordx8 (DEPTH loads in flight), 16 waves per CU, every CU busy.
