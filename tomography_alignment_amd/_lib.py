@@ -53,6 +53,7 @@ SIGNATURES = {
     "tomo_sync": (ctypes.c_int, [_c_vp]),
     "tomo_ctx_make_current": (ctypes.c_int, [_c_vp]),
     "tomo_set_option": (ctypes.c_int, [_c_vp, ctypes.c_char_p, ctypes.c_int]),
+    "tomo_ctx_set_cu_mask": (ctypes.c_int, [_c_vp, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int]),
     "tomo_check_geometry": (ctypes.c_int, [ctypes.POINTER(TomoGeom), ctypes.POINTER(ctypes.c_int)]),
     "tomo_set_geometry": (ctypes.c_int, [_c_vp, ctypes.POINTER(TomoGeom)]),
     "tomo_forward": (ctypes.c_int, [_c_vp, _c_dp, ctypes.c_int, _c_vp, _c_vp]),
@@ -211,6 +212,18 @@ class Context(object):
 
     def set_option(self, key, value):
         self.check(self.lib.tomo_set_option(self.handle, key.encode(), int(value)))
+
+    def set_cu_mask(self, cus=None):
+        """Restrict the compute stream to the CUs in `cus` (an iterable of CU indices; None: unrestricted)."""
+        if cus is None:
+            self.check(self.lib.tomo_ctx_set_cu_mask(self.handle, None, 0))
+            return
+        cus = sorted(set(int(c) for c in cus))
+        words = (max(cus) // 32 + 1) if cus else 1
+        m = (ctypes.c_uint32 * words)()
+        for c in cus:
+            m[c // 32] |= 1 << (c % 32)
+        self.check(self.lib.tomo_ctx_set_cu_mask(self.handle, m, words))
 
     def make_current(self):
         """Bind the CALLING thread to this context's GPU (HIP's current device is per thread; a new thread starts on device 0)."""

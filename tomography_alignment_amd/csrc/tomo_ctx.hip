@@ -150,6 +150,19 @@ extern "C" int tomo_ctx_make_current(tomo_ctx *ctx)
     return TOMO_OK;
 }
 
+extern "C" int tomo_ctx_set_cu_mask(tomo_ctx *ctx, const uint32_t *mask, int n_words)
+{
+    if (!ctx || n_words < 0 || (n_words > 0 && !mask)) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_ctx_set_cu_mask: bad args");
+    TOMO_HIP(ctx, hipSetDevice(ctx->device));
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipStream_t s = nullptr;
+    if (n_words == 0) TOMO_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    else TOMO_HIP(ctx, hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask));
+    (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = s;
+    return TOMO_OK;
+}
+
 extern "C" int tomo_set_option(tomo_ctx *ctx, const char *key, int value)
 {
     if (!ctx || !key) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
