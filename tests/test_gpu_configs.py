@@ -292,3 +292,58 @@ def test_config4_one_ranks_share_at_full_size(capsys):
     assert num / den < 1e-5 and e_err < 1e-5 and res["plain"][1][-1] < res["plain"][1][0]
     del res, s, d_b, truth
     comm.close()
+
+
+@pytest.mark.timeout(900)
+def test_config3_full_size_one_launch_of_1024_angles(capsys):
+    """BASELINE config 3 at FULL size in the -m gpu suite (until round 5 only bench.py ever launched 1024 angles at 1024^3,
+    the tests used 6 and 128): one forward and one exact adjoint over all 1024 angles of the 1024^3 volume --
+      * the 1024-angle launch agrees with launches of a FEW of its angles (rows 0, 1, 511, 512, 1023 of the sinogram taken from the big launch
+        against a 5-angle launch of the same poses: slot / row bookkeeping, live-block lists and atomics at full scale), tied to the oracle at
+        256^3 by the other tests of this file;
+      * adjointness <A x, y> = <x, A^T y> over all 1024 angles at 1e-5 (the gather back-projection against the atomic forward);
+      * two SIRT iterations with a ground truth run on the flat kernels, one launch each per pass, and reduce the error."""
+    from tomography_alignment_amd import _lib
+    from tomography_alignment_amd.backend import HipBackend
+    from tomography_alignment_amd.recon import sirt as sirt_mod
+    from tomography_alignment_amd.utilities.geometry import Geometry
+    from tomography_alignment_amd.utilities.generate_phantom import SHEPP_LOGAN
+    N, n = 1024, 1024
+    geo = Geometry(n, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
+    ctx = _lib.Context(0)
+    be = HipBackend(geo, ctx=ctx)
+    phi = np.linspace(0., np.pi, n)
+    poses = _lib.poses_array(phi, 0 * phi, 0 * phi, np.zeros((n, 3)), np.zeros(3))
+    x = be.phantom(be.empty(N ** 3), (N, N, N), SHEPP_LOGAN)
+    ax = be.forward(poses, x, be.empty(n * N * N))
+    pick = np.array([0, 1, 511, 512, 1023])
+    geo5 = Geometry(pick.size, np.array([N, N, N]), np.ones(3), np.array([N, N]), np.ones(2))
+    be5 = HipBackend(geo5, ctx=ctx)
+    ax5 = be5.forward(np.ascontiguousarray(poses[pick]), x, be5.empty(pick.size * N * N)).download().reshape(pick.size, -1)
+    worst = 0.0
+    for k, ip in enumerate(pick):
+        row = ax.view(int(ip) * N * N, N * N).download()
+        worst = max(worst, float(np.max(np.abs(row - ax5[k])) / np.max(np.abs(ax5[k]))))
+    del ax5, be5
+    # adjointness over all 1024 angles: y = a smooth positive sinogram made on the device (W-like: A applied to ones is not needed, y = A x scaled works)
+    be.ctx.set_geometry(geo)
+    y = be.empty(n * N * N)
+    be.copy(y, ax)
+    be.mul(y, ax)                                            # y = (A x)^2: not in the range of A, every plane of the object's band non-zero
+    aty = be.adjoint(poses, y, be.empty(N ** 3))
+    lhs, rhs = be.dot(ax, y), be.dot(x, aty)
+    adj = abs(lhs - rhs) / abs(lhs)
+    del y, aty
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    s = sirt_mod.SIRT(geo, ax, np.array([phi, 0 * phi, 0 * phi]).T, np.zeros((n, 3)), {"_backend": be, "ground_truth": x})
+    k_done, err = s.iterate_device(niter=2, positivity=True)
+    ctx.profile_enable(False)
+    counts = {k_: ctx.profile_get(k_)[0] for k_ in ("k_fwd_tile_flat", "k_adj_gather_flat", "k_fwd_tile", "k_adj_tile", "k_adj_tile_flat")}
+    with capsys.disabled():
+        print("\n[C3 full size: 1024^3 x 1024 angles in one launch] 1024-angle launch vs 5-angle launch %.2e; adjointness %.2e; SIRT error %.5f -> %.5f; launches %s"
+              % (worst, adj, err[0], err[-1], counts))
+    assert worst < 2e-6 and adj < 1e-5
+    # initialisation: A.1 and A^T.1 (one launch each) + two iterations: 3 forward and 3 back-projection launches, all on the flat kernels
+    assert k_done == 2 and err[1] < err[0] and counts == {"k_fwd_tile_flat": 3, "k_adj_gather_flat": 3, "k_fwd_tile": 0, "k_adj_tile": 0, "k_adj_tile_flat": 0}
+    del s, ax, x
