@@ -217,6 +217,20 @@ def main(out_path):
             out["%s_%s_nvol" % (tag, mode)], out["%s_%s_nslab" % (tag, mode)] = comm.n_vol_allreduce - v0, comm.n_slab_allreduce - s0
             out["%s_%s_nrs" % (tag, mode)], out["%s_%s_nag" % (tag, mode)] = getattr(comm, "n_rs", 0) - r0, getattr(comm, "n_ag", 0) - a0
             out["%s_%s_pipelined" % (tag, mode)] = s._iter_pipelined
+        # CGLS the same three ways (round 5: reduce-scatter per slab, gamma accumulated on the device over the own pieces, p updated piecewise and
+        # all-gathered with the next A p behind it; scalars through device accumulators + the communicator's small all-reduce)
+        from tomography_alignment_amd.recon import cgls_mpi
+        for mode in ("pipelined", "allreduce", "plain"):
+            comm.force_pipeline = mode != "plain"
+            c = cgls_mpi.CGLS(comm, geo, b.copy(), ang, xyz, options={"_backend": HipBackend(sirt_mpi.SIRT._shard_geometry(geo, mine), ctx=ctx)})
+            if mode == "plain":
+                c.n_pipeline_slabs = 1
+            c.shard_update = mode == "pipelined"
+            r0, a0, s0 = getattr(comm, "n_rs", 0), getattr(comm, "n_ag", 0), comm.n_slab_allreduce
+            crec, cerr = c.run_main_iteration(niter=5)
+            out["%s_cgls_%s_rec" % (tag, mode)], out["%s_cgls_%s_err" % (tag, mode)] = crec, cerr
+            out["%s_cgls_%s_counts" % (tag, mode)] = np.array([getattr(comm, "n_rs", 0) - r0, getattr(comm, "n_ag", 0) - a0, comm.n_slab_allreduce - s0,
+                                                               int(getattr(c, "_iter_pipelined", False))])
     align_rigid_stages(ctx, comm, out)
     if comm.rank == 0:
         np.savez(out_path, **out)

@@ -57,6 +57,14 @@ def test_sharded_sirt_world_2_on_the_gpu(tmp_path):
         assert int(two["%s_allreduce_nvol" % tag]) == 0 and int(two["%s_allreduce_nslab" % tag]) == 5 * 6 and int(two["%s_allreduce_nrs" % tag]) == 0
         assert int(two["%s_plain_nvol" % tag]) == 5 and int(two["%s_plain_nslab" % tag]) == 0
         assert one["%s_plain_err" % tag][-1] < one["%s_plain_err" % tag][0]
+        # CGLS (round 5): pipelined (reduce-scatter + all-gather per slab: 6 slabs x 5 iterations each), all-reduce form, plain -- world 2 = world 1
+        cref, cerr_ref = one["%s_cgls_plain_rec" % tag], one["%s_cgls_plain_err" % tag]
+        for w, name in ((one, "world 1"), (two, "world 2")):
+            for mode in ("pipelined", "allreduce", "plain"):
+                assert rel_max(w["%s_cgls_%s_rec" % (tag, mode)], cref) < 1e-5, (tag, name, mode, rel_max(w["%s_cgls_%s_rec" % (tag, mode)], cref))
+                assert np.allclose(w["%s_cgls_%s_err" % (tag, mode)], cerr_ref, rtol=1e-5), (tag, name, mode)
+        assert list(two["%s_cgls_pipelined_counts" % tag]) == [30, 30, 0, 1] and list(two["%s_cgls_allreduce_counts" % tag]) == [0, 0, 30, 1]
+        assert list(two["%s_cgls_plain_counts" % tag]) == [0, 0, 0, 0] and cerr_ref[-1] < cerr_ref[0]
     # examples/align_rigid.run(comm=...) on this world: each half of each outer iteration against the unsharded loop on
     # the same inputs -- sharded SIRT (slab pipeline forced at world 1 too) at 1e-5; the alignment pass of a rank's own projections against
     # the replicated reconstruction: its evaluations to 1e-9 (only the order of the float64 atomics inside a launch differs), its
