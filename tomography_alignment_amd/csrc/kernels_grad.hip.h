@@ -102,6 +102,9 @@ __device__ __forceinline__ void grad_finish(const GradC &gc, const TomoGeomC &g,
 #define TOMO_JS 8
 // PREC (option grad_v1_prec, a diagnostic of WHERE float32 costs accuracy; 0 = the production arithmetic): bit 0 = sample positions,
 // cells and fractions in float64 (no float32 in-block offsets), bit 1 = lerps and per-block sums in float64.
+#ifndef GRAD_MIN_WG
+#define GRAD_MIN_WG 1      // 256-thread work-groups per CU the register allocation of the v2 / v3 kernels must leave room for (= waves per SIMD)
+#endif
 template <bool FUSED, int PREC = 0>
 __global__ __launch_bounds__(256) void k_proj_grad(const ProjC *__restrict__ pcs, const GradC *__restrict__ gcs,
                                                    const float *__restrict__ vp, float *__restrict__ proj,
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256) void k_proj_grad(const ProjC *__restrict__ pcs
 // Only lanes inside their own [lo, hi) execute loads, all at addresses of samples inside the padded volume.
 // ------------------------------------------------------------------------------------------------
 template <bool FUSED>
-__global__ __launch_bounds__(256) void k_proj_grad_v2(const ProjC *__restrict__ pcs, const GradC *__restrict__ gcs,
+__global__ __launch_bounds__(256, GRAD_MIN_WG) void k_proj_grad_v2(const ProjC *__restrict__ pcs, const GradC *__restrict__ gcs,
                                                       const float *__restrict__ vp, float *__restrict__ proj,
                                                       float *__restrict__ grad, const float *__restrict__ bvec,
                                                       float *__restrict__ resid, double *__restrict__ red, TomoGeomC g,
@@ -333,7 +336,7 @@ __device__ __forceinline__ int dpp_shl1_i(int v) { return __builtin_amdgcn_updat
 __device__ __forceinline__ float dpp_shl1_f(float v) { return __builtin_bit_cast(float, dpp_shl1_i(__builtin_bit_cast(int, v))); }
 
 template <bool FUSED>
-__global__ __launch_bounds__(256) void k_proj_grad_v3(const ProjC *__restrict__ pcs, const GradC *__restrict__ gcs,
+__global__ __launch_bounds__(256, GRAD_MIN_WG) void k_proj_grad_v3(const ProjC *__restrict__ pcs, const GradC *__restrict__ gcs,
                                                       const float *__restrict__ vp, float *__restrict__ proj,
                                                       float *__restrict__ grad, const float *__restrict__ bvec,
                                                       float *__restrict__ resid, double *__restrict__ red, TomoGeomC g,

@@ -28,6 +28,25 @@
 #define ALY (ATY + 1)
 #define ALZ 64            // LDS row of ATZ + 1 planes padded to 64 dwords (256-B aligned rows: measured 20 % faster LDS atomics)
 #define ADJ_WAVES 8
+// Waves per work-group of the GENERAL tile kernels (k_tile) and the adjoint's projections per flush -- tuned in round 5 (1024^3 x 1024 angles,
+// +-1 deg, dense volume; profiles/round5_tile_waves_sweep.md).  Until then both ran 8 waves (two work-groups per CU by the 74 KB image):
+//   forward   8: 932 ms   10: 1108   12: 842   14: 915   16: 837   (16 with <= 64 VGPRs, two work-groups per CU: 833)
+//   adjoint   8 waves x 64 projections per flush: 1371 ms   10 x 80: 1989   12 x 96: 1239   12 x 192: 1226   12 x 384: 1218   14 x 112: 1730   16 x 128: 1539
+// Wave counts that are not a multiple of the 4 SIMDs leave SIMDs unevenly loaded (10, 14: slower than 8).  The forward has no barrier after
+// staging: ONE 16-wave work-group per CU beats two of 8; the adjoint flushes behind barriers every batch: two work-groups of 12 overlap
+// each other's flushes, and a longer batch means fewer of them.
+#ifndef TILE_FWD_WAVES
+#define TILE_FWD_WAVES 16
+#endif
+#ifndef TILE_ADJ_WAVES
+#define TILE_ADJ_WAVES 12
+#endif
+#ifndef TILE_ADJ_BATCH
+#define TILE_ADJ_BATCH 192
+#endif
+#ifndef TILE_MIN_WG
+#define TILE_MIN_WG 1
+#endif
 #define ADJ_BATCH 64
 
 struct AdjC {
@@ -240,8 +259,8 @@ __global__ __launch_bounds__(64) void k_tile_adj_live(const AdjC *__restrict__ p
 }
 
 // list != nullptr: a 1-D grid, work-group i takes the i-th live tile (nzt, nty: the tile grid the ids index); nullptr: a 3-D grid of tiles
-template <bool FWD>
-__global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
+template <bool FWD, int NW>
+__global__ __launch_bounds__(NW * 64, TILE_MIN_WG) void k_tile(const AdjC *__restrict__ pcs, int n_proj, float *__restrict__ proj,
                                                          float *__restrict__ vol, TomoGeomC g, const unsigned *__restrict__ absmax_bits,
                                                          float weight_bound, int tile_x0, const int *__restrict__ list, int nzt, int nty,
                                                          const int *__restrict__ zcum)
@@ -260,7 +279,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
     float scale = 1.f, inv_scale = 1.f;
     if (FWD) {
         bool any_nz = false;
-        for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) {
+        for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += NW * 64) {
             const int lz = e % ALZ, t2 = e / ALZ, ly = t2 % ALY, lx = t2 / ALY;
             const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
             float v = 0.f;
@@ -272,10 +291,10 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
     } else {
         const float ymax = __uint_as_float(*absmax_bits);
         if (!(ymax > 0.f)) return;                               // A^T 0 = 0 (vol already holds the right answer)
-        // |image| <= ADJ_BATCH * ymax * weight_bound  ->  keep it below 2^30
-        scale = 1073741824.f / ((float)min(n_proj, ADJ_BATCH) * ymax * weight_bound);
+        // |image| <= TILE_ADJ_BATCH * ymax * weight_bound  ->  keep it below 2^30
+        scale = 1073741824.f / ((float)min(n_proj, TILE_ADJ_BATCH) * ymax * weight_bound);
         inv_scale = 1.f / scale;
-        for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) acc[e] = 0;
+        for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += NW * 64) acc[e] = 0;
         __syncthreads();
     }
     const float bc[3] = {(float)x0 + 0.5f * ATX, (float)y0 + 0.5f * ATY, (float)z0 + 0.5f * ATZ};   // owned-box centre
@@ -284,10 +303,10 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
     const size_t n_det = (size_t)g.ndx * g.ndz;
     const float two_m32 = 2.3283064365386963e-10f;
 
-    const int batch = FWD ? n_proj : ADJ_BATCH;
+    const int batch = FWD ? n_proj : TILE_ADJ_BATCH;
     for (int ip0 = 0; ip0 < n_proj; ip0 += batch) {
         const int ip1 = min(n_proj, ip0 + batch);
-        for (int ip = ip0 + wv; ip < ip1; ip += ADJ_WAVES) {      // one wave owns a whole (tile, projection): set-up runs once
+        for (int ip = ip0 + wv; ip < ip1; ip += NW) {      // one wave owns a whole (tile, projection): set-up runs once
             const AdjC &c = pcs[ip];
             // Range work is CONSERVATIVE set-up in float32 (coordinates < 2^11: float32 error < 1e-3 voxel, margins 2e-2): it
             // only has to cover the owned samples; exact ownership is decided per sample from the fixed-point position.
@@ -435,7 +454,7 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile(const AdjC *__restrict_
         if (FWD) break;
         __syncthreads();
         // flush this batch: interior of the image is exclusively ours, the +1 faces are shared => global atomics
-        for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += ADJ_WAVES * 64) {
+        for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += NW * 64) {
             const int v = acc[e];
             if (v != 0) {
                 acc[e] = 0;

@@ -235,7 +235,9 @@ __global__ __launch_bounds__(ADJ_WAVES * 64) void k_tile_flat(const AdjC *__rest
 // the sample loop against every image.  NZT = 2 with 16 waves uses 148 KB of the 160 KB LDS for the two images, with the same
 // number of waves per CU as two 8-wave work-groups of the one-image kernel.
 // ------------------------------------------------------------------------------------------------
+#ifndef FZ_WAVES
 #define FZ_WAVES 16
+#endif
 // TX = x width of the tile footprint: 16 (with NZT = 2 z-stacked images: the default) or 32 (with NZT = 1: the "32 x 16 footprint"
 // of DESIGN.md section 4, built in round 3 to MEASURE what halving the tile crossings -- hence the float atomics -- costs in the
 // sample loop, whose per-entry broadcasts then serve one image instead of two; option fwd_flat_wide).

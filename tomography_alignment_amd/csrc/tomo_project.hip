@@ -285,7 +285,7 @@ static int forward_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
         unsigned char *t_flags = (unsigned char *)(t_list + 1 + n_tile);
         TOMO_LAUNCH(ctx, "k_fwd_live", k_tile_live, dim3((unsigned)n_tile), dim3(256), 0, d_vol, g, xt0, (int)grid.x, (int)grid.y, t_flags);
         TOMO_LAUNCH(ctx, "k_fwd_live", k_fwd_compact, dim3(1), dim3(1024), 0, (const unsigned char *)t_flags, (int)n_tile, t_list);
-        TOMO_LAUNCH(ctx, "k_fwd_tile", k_tile<true>, dim3((unsigned)n_tile), dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, d_proj, (float *)d_vol,
+        TOMO_LAUNCH(ctx, "k_fwd_tile", (k_tile<true, TILE_FWD_WAVES>), dim3((unsigned)n_tile), dim3(TILE_FWD_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, d_proj, (float *)d_vol,
                     g, (const unsigned *)nullptr, 1.f, xt0, (const int *)t_list, (int)grid.x, (int)grid.y, (const int *)nullptr);
     }
     return TOMO_OK;
@@ -464,7 +464,7 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
         TOMO_LAUNCH(ctx, "k_sino_zflags", k_tile_adj_live, dim3((unsigned)n_tile), dim3(64), 0, d_c + n_flat, n_proj - n_flat, g, xt0, (int)grid.x,
                     (int)grid.y, (const int *)d_zcum, t_flags);
         TOMO_LAUNCH(ctx, "k_sino_zflags", k_fwd_compact, dim3(1), dim3(1024), 0, (const unsigned char *)t_flags, (int)n_tile, t_list);
-        TOMO_LAUNCH(ctx, "k_adj_tile", k_tile<false>, dim3((unsigned)n_tile), dim3(ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, (float *)d_proj, d_vol, g,
+        TOMO_LAUNCH(ctx, "k_adj_tile", (k_tile<false, TILE_ADJ_WAVES>), dim3((unsigned)n_tile), dim3(TILE_ADJ_WAVES * 64), 0, d_c + n_flat, n_proj - n_flat, (float *)d_proj, d_vol, g,
                     (const unsigned *)d_absmax, (float)weight_bound, xt0, (const int *)t_list, (int)grid.x, (int)grid.y, (const int *)d_zcum);
     }
     return TOMO_OK;
