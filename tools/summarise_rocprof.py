@@ -30,6 +30,10 @@ ALIAS = {"k_adj_gather_flat<3>": "k_adj_gather_flat", "k_adj_gather_flat<6>": "k
 
 def short(name):
     k = name.split("(")[0].replace("void ", "")
+    if k.startswith("k_tile<true"):          # k_tile<FWD, waves per work-group> (round 5)
+        return "k_fwd_tile"
+    if k.startswith("k_tile<false"):
+        return "k_adj_tile"
     return ALIAS.get(k, k)
 
 
