@@ -1,5 +1,6 @@
-"""bench.py prints ONE JSON line with the driver's contract fields plus `roofline` and `cpu_baseline` (checked on a tiny
-workload so the test takes seconds)."""
+"""bench.py prints ONE JSON line with the driver's contract fields plus a compact `roofline` and `cpu_baseline` -- under 4 KB, whatever legs
+ran -- and writes everything it measured to the `--detail` file (checked on a tiny workload so the test takes seconds; the line's size at
+the full-size counters is held by tests/test_host_logic.py::test_bench_contract_line_stays_small_at_the_full_size_counters)."""
 import json
 import os
 import subprocess
@@ -12,17 +13,35 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _run(extra):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "64", "--angles", "48", "--steps", "2", "--warmup", "1"] + extra,
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, out.stdout
-    return json.loads(lines[0])
+def _run(extra, want_line=False):
+    """(the full record of the --detail file) or (stdout line, record)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "detail.json")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "64", "--angles", "48", "--steps", "2", "--warmup", "1", "--detail", path] + extra,
+                             capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1 and len(lines[0]) < 4096, out.stdout
+        line, detail = json.loads(lines[0]), json.load(open(path))
+    assert line["detail"] == path and line["value"] == detail["value"] and line["ms_per_step"] == detail["ms_per_step"]
+    return (line, detail) if want_line else detail
 
 
 def test_bench_json_contract():
-    d = _run([])
+    line, d = _run([], want_line=True)
+    # the stdout line: the driver's keys, typed, and the compact blocks
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                     ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(line[key], typ), key
+    assert line["vs_baseline"] is None and set(line["config"]) == {"workload", "sharding"}
+    lr = line["roofline"]
+    assert lr["bound"] == "hbm" and lr["peak"] == 8000.0 and abs(lr["frac"] - lr["achieved"] / lr["peak"]) < 1e-3 and lr["counters"] is None and lr["avg_launch_ms"] > 0
+    lc = line["cpu_baseline"]
+    assert lc["kind"] == "port" and lc["cores"] == 1 and lc["value"] > 0 and isinstance(lc["sample"], str)
+    assert line["value_dense_volume"] > 0 and line["value_tilted_poses"] > 0 and line["cgls_it_per_s"] > 0 and line["alignment_gradient"]["evals_per_sec"] > 0
+    assert line["align_rigid_e2e"]["wall_s"] > 0 and sum(line["kernel_ms_per_step"].values()) <= line["ms_per_step"]
+    # the record behind it
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
                      ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
         assert isinstance(d[key], typ), key

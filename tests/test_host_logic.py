@@ -487,6 +487,67 @@ def test_bench_launcher_and_roofline_logic_without_a_gpu(tmp_path, monkeypatch):
     assert len(live) == 16 and live == _lib.kernel_source_hash()
 
 
+def test_bench_contract_line_stays_small_at_the_full_size_counters(monkeypatch):
+    """round 5's stdout line was 25 KB (whole PMC dictionaries, per-outer tables) and the driver, which parses the last line
+    out of a bounded tail of stdout, parsed nothing.  The stdout line is now bench.contract_line(record); this holds it under bench.LINE_LIMIT
+    (4 KB) on (i) the very record that broke round 5 (profiles/round5_bench_1024.json, all legs, counter-backed rooflines) and (ii) rooflines
+    rebuilt from the COMMITTED full-size counter files for every workload key they hold, and checks that every driver key survives."""
+    import json
+    import bench
+    full = json.loads(open(os.path.join(ROOT, "profiles", "round5_bench_1024.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 20000                                        # the worst case on record
+    sq = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))
+    monkeypatch.setattr(_lib, "kernel_source_hash", lambda: sq["src_hash"])     # price against the committed counters whatever the sources are today
+    N, n_proj = 1024, 1024
+    records = [full]
+    for key, w in sq["workloads"].items():
+        rec = json.loads(json.dumps(full))
+        if key.startswith("C5_"):
+            per = {k: {"launches_per_pass": 1.0, "ms_per_pass": 60.0} for k in w["kernels"]}
+            rec["alignment_gradient"]["roofline"] = bench.grad_roofline(per, 720 * (4.0 * 512 ** 3 + 4.0 * 512 ** 2 + 28.0), key, 720 * 512.0 ** 3)
+            assert rec["alignment_gradient"]["roofline"]["counters"] is not None
+        else:
+            name = next(k for k in ("k_fwd_tile_flat", "k_fwd_tile") if k in w["kernels"])
+            rec["roofline"] = bench.make_roofline(name, 200.0, 1.0, n_proj * (4.0 * N ** 3 + 4.0 * N * N), key, n_proj * float(N) ** 3, 4.0 * n_proj * N * N)
+            rec["roofline"]["measured_d2d_copy_GBps"] = 5000.0
+            assert rec["roofline"]["counters"] is not None and len(json.dumps(rec["roofline"])) > 1500
+        records.append(rec)
+    for rec in records:
+        rec["detail_file"] = "gpurun_out/bench_detail.json"
+        line = bench.contract_line(rec)
+        assert len(line) < bench.LINE_LIMIT <= 4096 and "\n" not in line, len(line)
+        d = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                  "roofline", "cpu_baseline", "value_dense_volume", "value_tilted_poses", "cgls_it_per_s", "alignment_gradient", "align_rigid_e2e", "detail"):
+            assert k in d, k
+        assert set(d["config"]) == {"workload", "sharding"} and d["value"] == rec["value"] and d["ms_per_step"] == rec["ms_per_step"]
+        r = d["roofline"]
+        for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches_per_step", "traffic", "traffic_source",
+                  "hbm_algorithmic_frac", "hbm_counter_frac"):
+            assert k in r, k
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0 and "counters" not in r and "utilisation" not in r
+        c = d["cpu_baseline"]
+        assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["all_cores"]["cores"] >= 1 and len(c["sample"]) <= 230
+        assert c["reference"]["forward"]["s_per_angle"] > 0 and c["reference"]["gradient"]["s_per_eval"] > 0
+        assert d["alignment_gradient"]["evals_per_sec"] > 0 and d["align_rigid_e2e"]["wall_s"] > 0
+        assert sum(d["kernel_ms_per_step"].values()) <= d["ms_per_step"] * 1.02           # kernel time <= step time, checkable from the line
+    # nothing measured is dropped: the record itself goes to bench_detail.json / stderr (bench.emit)
+    import io
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        rfd, wfd = os.pipe()
+        err = io.StringIO()
+        monkeypatch.setattr(sys, "stderr", err)
+        bench.emit(dict(full), wfd, os.path.join(td, "detail.json"))
+        os.close(wfd)
+        got = os.read(rfd, 1 << 16).decode()
+        os.close(rfd)
+        assert got.count("\n") == 1 and len(got) < bench.LINE_LIMIT and json.loads(got)["detail"].endswith("detail.json")
+        back = json.load(open(os.path.join(td, "detail.json")))
+        assert back["alignment_gradient"]["roofline"]["counters"] == full["alignment_gradient"]["roofline"]["counters"] and back["kernels"] == full["kernels"]
+        assert "SQ_INSTS_VALU" in err.getvalue()
+
+
 def test_samples_per_ray_match_numpy_rounding():
     """n = int(|r0| / step) (utilities/ray_voxel_utilities.py:88) hangs on the rounding of a length that is an integer in exact
     arithmetic.  The library's host code (csrc/tomo_raycore.h, built here as a plain C++ program) rounds its 3-term inner products in

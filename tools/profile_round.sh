@@ -20,7 +20,7 @@ cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/$OUT
 for f in sq_counters.json pmc_traffic.json; do [ -f $R/profiles/$f ] && cp $R/profiles/$f $R/$OUT/$f; done
 if [ -z "$SKIP_STATS" ]; then
-    timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -o run -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${tag}_bench_under_rocprof.json 2> $R/gpurun_out/${tag}_stats.err || { echo "stats pass failed"; tail -5 $R/gpurun_out/${tag}_stats.err; exit 1; }
+    timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -o run -- python3 $R/bench.py --no-cpu-baseline --detail $R/gpurun_out/${tag}_bench_under_rocprof_detail.json > $R/gpurun_out/${tag}_bench_under_rocprof.json 2> $R/gpurun_out/${tag}_stats.err || { echo "stats pass failed"; tail -5 $R/gpurun_out/${tag}_stats.err; exit 1; }
     echo "stats pass done"
 fi
 SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
@@ -66,6 +66,7 @@ done
 cd $R
 if [ -z "$SKIP_STATS" ]; then
     cp gpurun_out/${tag}_bench_under_rocprof.json $OUT/${tag}_bench_under_rocprof.json
+    cp gpurun_out/${tag}_bench_under_rocprof_detail.json $OUT/${tag}_bench_under_rocprof_detail.json
     find gpurun_out/${tag}_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${tag}_kernel_stats.csv \;
 fi
 echo "summary done: $(ls $OUT)"
