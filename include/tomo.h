@@ -296,6 +296,21 @@ TOMO_API int tomo_trilinear_ray_interp(tomo_ctx *ctx, const int32_t *h_floor_poi
 TOMO_API int tomo_trilinear_ray_sparse(tomo_ctx *ctx, const int32_t *h_floor_points, const double *h_w_floor, int nx, int ny, int nz, int n_rays,
                               int n_points, int32_t *h_dat_inds, int32_t *h_det_inds, double *h_wts, int32_t *h_n_inds);
 
+/* The other f2py module, src.vox_wt_grad (round 6), as utilities/voxel_utilities.py:69-75,98-104 calls it:
+ *   det_img, grad_det_img = vox_wt_grad.bilinear_vox_interp(n_vox, floor_x, floor_z, alpha_x, alpha_z, rec, ndim_x, ndim_z, der_points)   src/vox_wt_grad.f90:1-55
+ *   dat_inds, det_inds, wts, n_inds = vox_wt_grad.bilinear_sparse(n_vox, floor_x, floor_z, alpha_x, alpha_z, ndim_x, ndim_z)              src/vox_wt_grad.f90:58-112
+ * HOST arrays as f2py passes them: floor_x, floor_z int32 [n_vox] (0-based floor pixel; the Fortran adds 1, :21-22), alpha_x, alpha_z, rec
+ * float32 [n_vox], der_points float32 Fortran (6, 3, n_vox) (element (q, a, i) at q + 6 a + 18 i; columns 1 and 3 are read, :27-28).  Outputs:
+ * det_img float32 Fortran (ndim_z, ndim_x), grad_det_img float32 Fortran (6, ndim_z, ndim_x), rows tx, ty, tz, phi, alpha, beta; dat_inds /
+ * det_inds int32 and wts float32 of length 4 * n_vox, pre-filled with -999 (:73-75), emission order voxel-major then (fx,fz), (fx+1,fz),
+ * (fx,fz+1), (fx+1,fz+1) with per-pixel bounds tests, det index x-fastest fx + ndim_x fz (:83).  Single precision in the reference's operation
+ * ORDER, including the order of the additions into a pixel (voxel order): bit-identical to the f2py module (tests/golden/g13). */
+TOMO_API int tomo_bilinear_vox_interp(tomo_ctx *ctx, int n_vox, const int32_t *h_floor_x, const int32_t *h_floor_z, const float *h_alpha_x,
+                             const float *h_alpha_z, const float *h_rec, int ndim_x, int ndim_z, const float *h_der_points, float *h_det_img,
+                             float *h_grad_det_img);
+TOMO_API int tomo_bilinear_sparse(tomo_ctx *ctx, int n_vox, const int32_t *h_floor_x, const int32_t *h_floor_z, const float *h_alpha_x, const float *h_alpha_z,
+                         int ndim_x, int ndim_z, int32_t *h_dat_inds, int32_t *h_det_inds, float *h_wts, int32_t *h_n_inds);
+
 /* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI)
  * Replaces mpi4py COMM_WORLD Allreduce(SUM) of recon/sirt_mpi.py:68,103 and recon/cgls_mpi.py:55,98
  * and the scalar allreduce of recon/sirt_mpi.py:110. */

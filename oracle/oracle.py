@@ -421,6 +421,30 @@ def vox_forward_proj_grad(geo, alpha, beta, phi, xyz_shift, cor_shift3, rec):
     return img.ravel(), grad.reshape(6, -1)
 
 
+def bilinear_sparse(n_vox, floor_x, floor_z, alpha_x, alpha_z, ndim_x, ndim_z):
+    """src/vox_wt_grad.f90:58-112 with the f2py module's signature and returns: (dat_inds, det_inds, wts, n_inds), length 4*n_vox,
+    -999 beyond n_inds (:73-75).  Pinned bit for bit to the f2py module by tests/golden/g13."""
+    n = int(n_vox)
+    fx, fz = np.ascontiguousarray(floor_x, np.int32), np.ascontiguousarray(floor_z, np.int32)
+    ax, az = np.ascontiguousarray(alpha_x, np.float32), np.ascontiguousarray(alpha_z, np.float32)
+    dat, det, wts = np.full(4 * n, -999, np.int32), np.full(4 * n, -999, np.int32), np.full(4 * n, -999.0, np.float32)
+    k = _lib().orc_bilinear_sparse(ctypes.c_int64(n), _p(fx), _p(fz), _p(ax), _p(az), int(ndim_x), int(ndim_z), _p(dat), _p(det), _p(wts))
+    return dat, det, wts, int(k)
+
+
+def bilinear_vox_interp(n_vox, floor_x, floor_z, alpha_x, alpha_z, rec, ndim_x, ndim_z, der_points):
+    """src/vox_wt_grad.f90:1-55 with the f2py module's signature and returns: det_img (ndim_z, ndim_x), grad_det_img (6, ndim_z, ndim_x),
+    float32, Fortran order.  Pinned bit for bit to the f2py module by tests/golden/g13."""
+    n, ndx, ndz = int(n_vox), int(ndim_x), int(ndim_z)
+    fx, fz = np.ascontiguousarray(floor_x, np.int32), np.ascontiguousarray(floor_z, np.int32)
+    ax, az = np.ascontiguousarray(alpha_x, np.float32), np.ascontiguousarray(alpha_z, np.float32)
+    rec32 = np.ascontiguousarray(np.asarray(rec).ravel(), np.float32)
+    der = np.ascontiguousarray(der_points, np.float32)               # C-order (6, 3, n_vox): what orc_bilinear_vox_interp indexes
+    img, grad = np.zeros(ndx * ndz, np.float32), np.zeros(6 * ndx * ndz, np.float32)
+    _lib().orc_bilinear_vox_interp(ctypes.c_int64(n), _p(fx), _p(fz), _p(ax), _p(az), _p(rec32), ndx, ndz, _p(der), _p(img), _p(grad))
+    return np.reshape(img, (ndz, ndx), order='F'), np.reshape(grad, (6, ndz, ndx), order='F')
+
+
 # ----------------------------------------------------------------------------------------
 # solvers restated on top of forward/adjoint callables (recon/sirt.py, recon/cgls.py)
 # ----------------------------------------------------------------------------------------

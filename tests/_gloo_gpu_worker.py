@@ -122,6 +122,17 @@ def align_rigid_stages(ctx, comm, out):
     geo = Geometry(n_proj, np.array([N] * 3), np.ones(3), np.array([N, N]), np.ones(2))
     full = HipBackend(geo, ctx=ctx)
     b = full.forward(_lib.poses_array(phi, alpha, beta, xyz, np.zeros(3)), full.upload(x), full.empty(n_proj * N * N)).download().reshape(n_proj, N, N)
+
+    def from_rank0(a):
+        """rank 0's copy on every rank: whatever a rank computes with the forward projectors (float32 atomics into the sinogram: equal up to
+        the order of the additions) differs in the last bits from the same computation on another rank -- the measured projections, and the
+        unsharded reference reconstruction.  Every rank must start from, compare against and continue from the SAME arrays."""
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        comm.dist.broadcast(t, src=0)
+        return t.numpy()
+
+    b = from_rank0(b)
     data = dict(projections=b, phi=phi, phantom=x, xyz=xyz, alpha=alpha, beta=beta)
     mine = np.array_split(np.arange(n_proj), comm.size)[comm.rank]
     shard_be = lambda: HipBackend(sirt_mpi.SIRT._shard_geometry(geo, mine), ctx=ctx)      # noqa: E731
@@ -134,14 +145,6 @@ def align_rigid_stages(ctx, comm, out):
     out["e_pipelined"] = bool(align_rigid.run.last_loop.solver._iter_pipelined)
     ref = align_rigid.OuterLoop(data, backend=HipBackend(geo, ctx=ctx), comm=SingleComm())
     shd = align_rigid.OuterLoop(data, backend=shard_be(), comm=comm)
-    def from_rank0(a):
-        """rank 0's copy on every rank: the unsharded reference runs on each rank, and two runs of it agree only to float32 atomics /
-        to what the optimiser makes of them -- every rank must compare against (and continue from) the SAME reference"""
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(a))
-        comm.dist.broadcast(t, src=0)
-        return t.numpy()
-
     for stage in (0, 1):
         (k_r, err_r), (k_s, err_s) = ref.reconstruct(8), shd.reconstruct(8)
         a_r, a_s = from_rank0(ref.download()), shd.download()
@@ -149,13 +152,16 @@ def align_rigid_stages(ctx, comm, out):
         out["st_sirt%d_rec" % stage] = float(np.max(np.abs(a_s - a_r)) / np.max(np.abs(a_r)))
         out["st_sirt%d_err" % stage] = float(np.max(np.abs(err_s - err_r) / err_r)) if k_r == k_s else 1.0
         shd.d_rec.upload(a_r)
+        keep = (ref.alpha_rec.copy(), ref.beta_rec.copy(), ref.xyz_rec.copy())
+        r_0 = ref.align()                                      # the same pass twice from the same state: bit-identical (round 6)
+        ref.alpha_rec, ref.beta_rec, ref.xyz_rec = keep
         r_r, r_s = ref.align(), shd.align()
+        out["st_repeat%d_x" % stage] = float(np.max(np.abs(r_0["x"] - r_r["x"])))
         r_r["x"], r_r["fun"] = from_rank0(r_r["x"]), from_rank0(r_r["fun"])
         ref.alpha_rec, ref.beta_rec, ref.xyz_rec = from_rank0(ref.alpha_rec), from_rank0(ref.beta_rec), from_rank0(ref.xyz_rec)
-        # On the GPU the pass is not reproducible to the last digits even against ITSELF (the float64 atomics of the fused reduction
-        # complete in any order, and L-BFGS-B on the piecewise-trilinear cost amplifies that): the optimisers' outcomes are compared
-        # loosely, the EVALUATIONS the pass is made of tightly -- the same poses (the unsharded pass's result) through both
-        # evaluators: the rank's own-row table, its row map and its centre-of-rotation shifts against the full table
+        # Round 6: the fused reduction is deterministic (fixed-order second stage), so the pass reproduces itself and the sharded pass is the
+        # unsharded one bit for bit; the EVALUATIONS the pass is made of are compared as well -- the same poses (the unsharded pass's result)
+        # through both evaluators: the rank's own-row table, its row map and its centre-of-rotation shifts against the full table
         out["st_align%d_x" % stage] = float(np.max(np.abs(r_s["x"] - r_r["x"])))
         out["st_align%d_fun" % stage] = float(np.max(np.abs(r_s["fun"] - r_r["fun"]) / np.maximum(np.abs(r_r["fun"]), 1e-30)))
         from tomography_alignment_amd import alignment

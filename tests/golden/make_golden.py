@@ -468,7 +468,62 @@ def g12():
     save("g12_sirt_regularized_gd", **out)
 
 
+# ------------------------------------------------------------------ G13 the f2py module src.vox_wt_grad at ARRAY level
+def g13():
+    """What utilities/voxel_utilities.py:51-108 hands to `vox_wt_grad.bilinear_sparse` / `.bilinear_vox_interp` (the f2py module built from the
+    untouched src/vox_wt_grad.f90) and what the module returns -- recorded by a pass-through around the two functions while the reference's own
+    callers run, so the twin `tomography_alignment_amd/src/vox_wt_grad.py` can be fed the very arrays (VERDICT r5 missing 3).  12 x 10 x 9 volume on a
+    NON-square 14 x 11 detector (ndim_x = det_shape[0] = 14, ndim_z = det_shape[1] = 11 pins the (ndim_z, ndim_x) / x-fastest layouts); pose 0 generic,
+    pose 1 shifted so far that voxels leave the detector on two sides (per-pixel bounds tests, -999 tails)."""
+    from src import vox_wt_grad as real
+    rng = np.random.default_rng(13)
+    shape, ndet = np.array([12, 10, 9]), np.array([14, 11])
+    rec = rng.uniform(0.0, 1.0, shape).astype(np.float32)
+    rec[:3] = 0.0
+    calls = []
+
+    def spy(name):
+        fn = getattr(real, name)
+
+        def wrapped(*a):
+            out = fn(*a)
+            calls.append((name, a, out))
+            return out
+        return wrapped
+
+    voxel_utilities.vox_wt_grad = types.SimpleNamespace(bilinear_sparse=spy("bilinear_sparse"), bilinear_vox_interp=spy("bilinear_vox_interp"))
+    out = dict(shape=shape, ndet=ndet, rec=rec)
+    poses = [(np.deg2rad(1.7), np.deg2rad(-2.3), 0.8, np.array([0.6, 0.3, -1.2]), np.array([0.4, 0.0, -0.3])),
+             (np.deg2rad(-3.0), np.deg2rad(2.0), 2.4, np.array([6.5, -1.0, -5.25]), np.zeros(3))]
+    try:
+        for i, (al, be, ph, t, cor) in enumerate(poses):
+            geo = geometry.Geometry(1, shape, np.ones(3), ndet, np.ones(2))
+            geo.cor_shift = cor
+            del calls[:]
+            d, r, w = voxel_utilities.forward_sparse(geo, al, be, ph, t)
+            img, grad = voxel_utilities.forward_proj_grad(geo, al, be, ph, t, rec)
+            (n0, a0, o0), (n1, a1, o1) = calls
+            assert n0 == "bilinear_sparse" and n1 == "bilinear_vox_interp"
+            out.update({"p%d_pose" % i: np.array([al, be, ph]), "p%d_xyz" % i: t, "p%d_cor" % i: cor,
+                        # bilinear_sparse(n_vox, floor_x, floor_z, alpha_x, alpha_z, ndim_x, ndim_z) -> dat_inds, det_inds, wts, n_inds
+                        "p%d_n_vox" % i: np.array(a0[0]), "p%d_floor_x" % i: np.array(a0[1]), "p%d_floor_z" % i: np.array(a0[2]),
+                        "p%d_alpha_x" % i: np.array(a0[3]), "p%d_alpha_z" % i: np.array(a0[4]), "p%d_ndim_x" % i: np.array(a0[5]), "p%d_ndim_z" % i: np.array(a0[6]),
+                        "p%d_dat_inds" % i: np.array(o0[0]), "p%d_det_inds" % i: np.array(o0[1]), "p%d_wts" % i: np.array(o0[2]), "p%d_n_inds" % i: np.array(o0[3]),
+                        # bilinear_vox_interp(n_vox, floor_x, floor_z, alpha_x, alpha_z, rec, ndim_x, ndim_z, der_points) -> det_img, grad_det_img
+                        "p%d_rec_arg" % i: np.array(a1[5]), "p%d_der" % i: np.array(a1[8]),
+                        "p%d_det_img" % i: np.array(o1[0]), "p%d_grad_det_img" % i: np.array(o1[1]),
+                        "p%d_det_img_fortran" % i: np.array(int(o1[0].flags["F_CONTIGUOUS"])), "p%d_grad_fortran" % i: np.array(int(o1[1].flags["F_CONTIGUOUS"])),
+                        # what the callers make of them (layout handling: .ravel() / .reshape(6, -1) of the returned arrays)
+                        "p%d_caller_img" % i: img, "p%d_caller_grad" % i: grad, "p%d_caller_dat" % i: d, "p%d_caller_det" % i: r, "p%d_caller_wts" % i: w})
+            for k in (1, 2, 3, 4):
+                assert np.array_equal(a0[k], a1[k])
+            print("   g13 pose %d: n_vox %d, n_inds %d of %d, det_img %s %s, grad %s %s" % (i, a0[0], o0[3], 4 * a0[0], o1[0].shape, o1[0].dtype, o1[1].shape, o1[1].dtype))
+    finally:
+        voxel_utilities.vox_wt_grad = real
+    save("g13_vox_wt_grad_arrays", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g7", "g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g7", "g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()[w]()

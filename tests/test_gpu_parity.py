@@ -176,9 +176,55 @@ def test_cost_grad_fused_vs_oracle(PM, orc, shepp32):
     # row-indexed form (tomo_cost_grad_rows): a subset of the poses against their rows of the resident table
     pick = np.array([2, 0])
     c2, g2 = be.cost_grad(np.ascontiguousarray(poses[pick]), be.upload(shepp32), be.upload(b), rows=pick)
-    assert np.allclose(c2, cost[pick], rtol=1e-12) and np.allclose(g2, g6[pick], rtol=1e-9, atol=1e-9)
+    # round 6: the fused reduction adds the work-groups' partial sums in a fixed order -- a pose's seven numbers do not depend on the batch
+    assert np.array_equal(c2, cost[pick]) and np.array_equal(g2, g6[pick])
     with pytest.raises(_lib.TomoError):
         be.cost_grad(np.ascontiguousarray(poses[:1]), be.upload(shepp32), be.upload(b), rows=np.array([3]))
+
+
+@pytest.mark.parametrize("shape,ndet", [((64, 64, 64), (64, 64)), ((50, 44, 150), (70, 210)), ((400, 380, 340), (402, 350))])
+def test_fused_cost_gradient_is_deterministic(PM, shape, ndet):
+    """the reference's cost and gradient (utilities/alignment_functions.py:16-37) are deterministic; until round 5
+    the fused kernels ended in one float64 atomicAdd per work-group, so two identical calls differed in the last digits and L-BFGS-B turned
+    that into 1e-4 px.  Now: work-group partials + a fixed-order second stage (k_cost_grad_reduce) --
+      * the same call twice: bit-identical;
+      * a pose evaluated alone, in a shuffled batch, in a batch of duplicates, against a row-indexed table: the same seven numbers, bit for bit
+        (the partial layout is a function of the rays a work-group owns, not of the launch);
+      * every kernel variant on its own (1, 2, 3) and the per-pose choice (4);
+      * the third shape takes the cache-ordered grid (z chunk slowest, XCD swizzle off: 101 x groups) when several poses share a launch and the
+        plain order for one pose: same numbers."""
+    from tomography_alignment_amd import _lib
+    rng = np.random.default_rng(23)
+    n = 7
+    geo, _ = geo_pair(n, None, ndet=ndet, shape=shape)
+    be = PM(geo).backend
+    x = rng.uniform(0.0, 1.0, shape).astype(np.float32)
+    x[: shape[0] // 5] = 0.0                                       # a non-trivial box of non-zero voxels
+    phi = np.linspace(0.1, 3.0, n)
+    alpha, beta = np.deg2rad(rng.uniform(-2, 2, n)), np.deg2rad(rng.uniform(-2, 2, n))
+    alpha[:2] = beta[:2] = 0.0                                     # both tilt groups present (variant 4: v2 for these, v3 for the rest)
+    xyz = rng.uniform(-3, 3, (n, 3))
+    poses = _lib.poses_array(phi, alpha, beta, xyz, np.zeros(3))
+    vol = be.upload(x)
+    b = be.forward(poses, vol, be.empty(n * be.n_det))
+    b.upload(b.download() + rng.standard_normal(n * be.n_det).astype(np.float32))
+    for v in (4, 1, 2, 3):
+        be.ctx.set_option("grad_variant", v)
+        c0, g0 = be.cost_grad(poses, vol, b)
+        assert np.all(np.isfinite(c0)) and np.all(c0 > 0) and np.all(np.abs(g0).max(axis=1) > 0)
+        for _ in range(3):
+            c1, g1 = be.cost_grad(poses, vol, b)
+            assert np.array_equal(c1, c0) and np.array_equal(g1, g0), v
+        perm = rng.permutation(n)
+        c2, g2 = be.cost_grad(np.ascontiguousarray(poses[perm]), vol, b, rows=perm)
+        assert np.array_equal(c2, c0[perm]) and np.array_equal(g2, g0[perm]), v
+        for i in (0, n - 1):
+            c3, g3 = be.cost_grad(np.ascontiguousarray(poses[i:i + 1]), vol, b, rows=np.array([i]))
+            assert c3[0] == c0[i] and np.array_equal(g3[0], g0[i]), (v, i)
+        dup = np.array([3, 3, 0, 3, 5, 0])
+        c4, g4 = be.cost_grad(np.ascontiguousarray(poses[dup]), vol, b, rows=dup)
+        assert np.array_equal(c4, c0[dup]) and np.array_equal(g4, g0[dup]), v
+    be.ctx.set_option("grad_variant", 4)
 
 
 @pytest.mark.parametrize("shape,ndet,step,n_proj", [((20, 24, 70), (20, 70), 1.0, 3),     # ragged, nz > 64, not multiple of 64
@@ -808,6 +854,78 @@ def test_f2py_signature_twins_vs_reference_golden(shepp32):
     A.sort_indices()
     assert np.array_equal(A.indptr, g1["b_indptr"]) and np.array_equal(A.indices, g1["b_indices"]) and rel_max(A.data, g1["b_data"]) < 1e-6
     print("f2py twins: trilinear_ray_interp vs the float64 oracle %.1e; trilinear_ray_sparse reproduces G1 b's CSR" % worst)
+
+
+def test_vox_wt_grad_twin_vs_reference_golden():
+    """VERDICT r5 missing 3 / next 3: `src.vox_wt_grad.bilinear_sparse / bilinear_vox_interp` with the f2py module's call signatures
+    (src/vox_wt_grad.f90:1-55,58-112; called at utilities/voxel_utilities.py:69,98) on the library (tomo_bilinear_sparse / tomo_bilinear_vox_interp,
+    csrc/tomo_f2py.hip):
+      * G13 -- fed the very arrays the reference's Python handed to its f2py module, against what that module returned: BIT-IDENTICAL (float32 in
+        the reference's operation order, additions into a pixel in voxel order), -999 tails, shapes and Fortran memory order of the returns;
+      * G8 -- through the numpy of utilities/voxel_utilities.py:59-67,88-96 (restated by this package's mirror helpers) against the reference's
+        forward_sparse CSR and forward_proj_grad outputs;
+      * edge cases: n_vox = 0, every voxel off the detector, a 1 x 1 detector."""
+    from scipy import sparse
+    from tomography_alignment_amd.src import vox_wt_grad
+    from tomography_alignment_amd.utilities import voxel_utilities as vu
+    g = golden("g13_vox_wt_grad_arrays")
+    for i in range(2):
+        a = lambda k: g["p%d_%s" % (i, k)]      # noqa: E731
+        n, ndx, ndz = int(a("n_vox")), int(a("ndim_x")), int(a("ndim_z"))
+        dat, det, wts, k = vox_wt_grad.bilinear_sparse(n, np.asfortranarray(a("floor_x")), np.asfortranarray(a("floor_z")), np.asfortranarray(a("alpha_x")),
+                                                       np.asfortranarray(a("alpha_z")), ndx, ndz)
+        assert k == int(a("n_inds")) and dat.shape == (4 * n,) and dat.dtype == np.int32 and det.dtype == np.int32 and wts.dtype == np.float32
+        assert np.array_equal(dat, a("dat_inds")) and np.array_equal(det, a("det_inds")) and np.array_equal(wts, a("wts"))
+        img, grad = vox_wt_grad.bilinear_vox_interp(n, a("floor_x"), a("floor_z"), a("alpha_x"), a("alpha_z"), np.asfortranarray(a("rec_arg")), ndx, ndz,
+                                                    np.asfortranarray(a("der")))
+        assert img.shape == (ndz, ndx) and grad.shape == (6, ndz, ndx) and img.dtype == np.float32 and img.flags["F_CONTIGUOUS"] and grad.flags["F_CONTIGUOUS"]
+        assert np.array_equal(img, a("det_img")) and np.array_equal(grad, a("grad_det_img"))
+        assert np.array_equal(img.ravel(), a("caller_img")) and np.array_equal(grad.reshape(6, -1), a("caller_grad"))
+        # a C-ordered der_points is converted as f2py converts it
+        img2, grad2 = vox_wt_grad.bilinear_vox_interp(n, a("floor_x"), a("floor_z"), a("alpha_x"), a("alpha_z"), a("rec_arg"), ndx, ndz, np.ascontiguousarray(a("der")))
+        assert np.array_equal(img2, img) and np.array_equal(grad2, grad)
+    # G8 through the caller's numpy (utilities/voxel_utilities.py:59-67,88-96)
+    g8 = golden("g8_voxel_splat")
+    x = golden("g7_phantom")["shepp16"].astype(np.float32)
+    for i in range(2):
+        geo, _ = geo_pair(1, 16)
+        rc = vu.rigid_transformation(geo.vox_centers, g8["alpha"][i], g8["beta"][i], g8["phi"][i], g8["xyz"][i])
+        orig = geo.vox_origin - g8["cor"][i]
+        fx, fz = np.floor(rc[0] - orig[0]).astype(np.int32), np.floor(rc[2] - orig[2]).astype(np.int32)
+        ax, az = (rc[0] - orig[0] - fx).astype(np.float32), (rc[2] - orig[2] - fz).astype(np.float32)
+        dat, det, wts, k = vox_wt_grad.bilinear_sparse(geo.n_vox, fx, fz, ax, az, 16, 16)
+        A = sparse.csr_matrix(sparse.coo_matrix((wts[:k], (det[:k], dat[:k])), shape=(256, 4096)))
+        ref = sparse.csr_matrix((g8["s%d_data" % i], g8["s%d_indices" % i], g8["s%d_indptr" % i]), shape=tuple(g8["s%d_shape" % i]))
+        A.sum_duplicates(); A.sort_indices()
+        assert np.array_equal(A.indptr, ref.indptr) and np.array_equal(A.indices, ref.indices) and np.array_equal(A.data, ref.data)
+        der = vu.derivative_rigid(geo.vox_centers, g8["alpha"][i], g8["beta"][i], g8["phi"][i], g8["xyz"][i]).astype(np.float32)
+        img, grad = vox_wt_grad.bilinear_vox_interp(geo.n_vox, fx, fz, ax, az, np.asfortranarray(x.ravel()), 16, 16, np.asfortranarray(der))
+        assert np.array_equal(img.ravel(), g8["img%d" % i]) and rel_max(grad.reshape(6, -1), g8["grad%d" % i]) < 1e-6
+        print("vox_wt_grad twin, G8 pose %d: image identical, gradient rel-max %.1e" % (i, rel_max(grad.reshape(6, -1), g8["grad%d" % i])))
+    # edge cases
+    z = np.zeros(0, np.int32)
+    dat, det, wts, k = vox_wt_grad.bilinear_sparse(0, z, z, z.astype(np.float32), z.astype(np.float32), 3, 2)
+    assert k == 0 and dat.size == 0
+    img, grad = vox_wt_grad.bilinear_vox_interp(0, z, z, z.astype(np.float32), z.astype(np.float32), z.astype(np.float32), 3, 2, np.zeros((6, 3, 0), np.float32))
+    assert img.shape == (2, 3) and not img.any() and not grad.any()
+    far = np.full(5, 100, np.int32)
+    h = np.full(5, 0.25, np.float32)
+    dat, det, wts, k = vox_wt_grad.bilinear_sparse(5, far, -far, h, h, 4, 4)
+    assert k == 0 and np.all(dat == -999) and np.all(wts == -999.0)
+    # 1 x 1 detector: voxels at floor (-1, -1), (0, -1), (-1, 0), (0, 0) reach pixel (0, 0) through corners 3, 2, 1, 0 in that voxel order
+    fx1, fz1 = np.array([-1, 0, -1, 0, 5], np.int32), np.array([-1, -1, 0, 0, 5], np.int32)
+    a1, b1 = np.array([0.3, 0.6, 0.1, 0.9, 0.5], np.float32), np.array([0.2, 0.7, 0.4, 0.8, 0.5], np.float32)
+    r1 = np.array([1.5, 2.5, 3.5, 4.5, 9.0], np.float32)
+    dat, det, wts, k = vox_wt_grad.bilinear_sparse(5, fx1, fz1, a1, b1, 1, 1)
+    assert k == 4 and list(dat[:4]) == [0, 1, 2, 3] and list(det[:4]) == [0, 0, 0, 0]
+    f = np.float32
+    want_w = [a1[0] * b1[0], (f(1) - a1[1]) * b1[1], a1[2] * (f(1) - b1[2]), (f(1) - a1[3]) * (f(1) - b1[3])]
+    assert np.array_equal(wts[:4], np.array(want_w, np.float32))
+    img, _ = vox_wt_grad.bilinear_vox_interp(5, fx1, fz1, a1, b1, r1, 1, 1, np.zeros((6, 3, 5), np.float32))
+    acc = f(0)
+    for j, (wx, wz) in enumerate([(a1[0], b1[0]), (f(1) - a1[1], b1[1]), (a1[2], f(1) - b1[2]), (f(1) - a1[3], f(1) - b1[3])]):
+        acc = f(acc + f(f(r1[j] * wx) * wz))
+    assert img.shape == (1, 1) and img[0, 0] == acc
 
 
 def test_context_used_from_a_helper_thread(PM, orc, shepp32):

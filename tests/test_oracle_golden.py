@@ -295,3 +295,24 @@ def test_g10_cell_face_exemption_is_reference_behaviour(capsys):
     assert n_flip >= 3                                                        # ... and they do occur (6 rays in this fixture)
     with capsys.disabled():
         print("\n[G10 64^3, every face a jump] " + "\n[G10] ".join(lines))
+
+
+def test_g13_vox_wt_grad_array_level_bit_for_bit():
+    """G13: the arrays the reference's utilities/voxel_utilities.py hands to its f2py module `src.vox_wt_grad` and what the module returned
+    (recorded around the real module by tests/golden/make_golden.py::g13).  The oracle's restatement of src/vox_wt_grad.f90, called with the
+    f2py signature, returns the same BITS: single precision, products left to right, additions into a pixel in voxel order, -999 tails,
+    x-fastest detector index, Fortran-ordered (ndim_z, ndim_x) outputs.  This is what pins `tomography_alignment_amd/src/vox_wt_grad.py` on the GPU."""
+    g = golden("g13_vox_wt_grad_arrays")
+    for i in range(2):
+        a = lambda k: g["p%d_%s" % (i, k)]      # noqa: E731
+        n, ndx, ndz = int(a("n_vox")), int(a("ndim_x")), int(a("ndim_z"))
+        assert (ndx, ndz) == (14, 11) and n == 12 * 10 * 9
+        dat, det, wts, k = orc.bilinear_sparse(n, a("floor_x"), a("floor_z"), a("alpha_x"), a("alpha_z"), ndx, ndz)
+        assert k == int(a("n_inds")) and 0 < k < 4 * n
+        assert np.array_equal(dat, a("dat_inds")) and np.array_equal(det, a("det_inds")) and np.array_equal(wts, a("wts")) and wts.dtype == np.float32
+        assert np.all(dat[k:] == -999) and np.all(wts[k:] == -999.0)
+        img, grad = orc.bilinear_vox_interp(n, a("floor_x"), a("floor_z"), a("alpha_x"), a("alpha_z"), a("rec_arg"), ndx, ndz, a("der"))
+        assert img.shape == (ndz, ndx) and grad.shape == (6, ndz, ndx) and img.flags["F_CONTIGUOUS"] and int(a("det_img_fortran")) == 1
+        assert np.array_equal(img, a("det_img")) and np.array_equal(grad, a("grad_det_img"))
+        assert np.array_equal(img.ravel(), a("caller_img")) and np.array_equal(grad.reshape(6, -1), a("caller_grad"))     # voxel_utilities.py:105
+        assert np.abs(img).max() > 0 and np.abs(grad).max() > 0

@@ -94,6 +94,8 @@ SIGNATURES = {
     "tomo_csr_fetch": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp]),
     "tomo_trilinear_ray_interp": (ctypes.c_int, [_c_vp, _c_vp, _c_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
     "tomo_trilinear_ray_sparse": (ctypes.c_int, [_c_vp, _c_vp, _c_dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp, _c_vp, _c_dp, _c_vp]),
+    "tomo_bilinear_vox_interp": (ctypes.c_int, [_c_vp, ctypes.c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, _c_vp, _c_vp, _c_vp]),
+    "tomo_bilinear_sparse": (ctypes.c_int, [_c_vp, ctypes.c_int, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
     "tomo_comm_get_unique_id": (ctypes.c_int, [_c_vp]),
     "tomo_comm_init": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int]),
     "tomo_comm_destroy": (ctypes.c_int, [_c_vp]),

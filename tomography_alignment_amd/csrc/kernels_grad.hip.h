@@ -18,18 +18,26 @@ __device__ __forceinline__ int med3_i32_s(int a_uniform, int b, int c)      // m
     return r;
 }
 
+// work-groups of the gradient kernels per projection (4 detector-x rows x 64 detector-z pixels each), and a work-group's index among them
+__host__ __device__ __forceinline__ int grad_wg_per_proj(const TomoGeomC &g) { return ((g.ndx + 3) / 4) * ((g.ndz + 63) / 64); }
+
 // ------------------------------------------------------------------------------------------------
 // Shared tail of the gradient kernels: the per-ray 9x3 pose Jacobian applied ONCE to the accumulated S0 = sum_j grad_j and
 // S1 = sum_j sf_j grad_j (utilities/ray_voxel_utilities.py:38-49; same algebra as src/ray_wt_grad.f90:136-149), then either the
 // plain outputs (proj[n_det], grad[6][n_det]; row_order 1 = the Fortran twin's tx,ty,tz,alpha,beta,phi,
 // src/external_forward_projection.f90:56-69) or, FUSED, the residual and the 7 reductions of
-// utilities/alignment_functions.py:23-37,124,146 (wave shuffles -> LDS -> one double atomic per work-group and sum).
+// utilities/alignment_functions.py:23-37,124,146: wave shuffles -> LDS -> the work-group's seven float64 partial sums are WRITTEN to
+// red[(ipl * 7 + k) * n_wg + w] (ipl = the projection's index in this launch, w = the work-group's index inside the projection,
+// fixed by the rays it owns, not by the grid order) and k_cost_grad_reduce adds them in the order of w.  No atomics: the reference's
+// sums (utilities/alignment_functions.py:16-37) are deterministic and so are these -- the same pose gives the same seven numbers
+// bit for bit, in whatever batch it is evaluated (round 6; until round 5 one float64 atomicAdd per work-group, whose completion
+// order L-BFGS-B amplified to 1e-4 px between two identical passes).
 // Must be reached by every thread of the work-group (FUSED ends in a barrier).
 // ------------------------------------------------------------------------------------------------
 template <bool FUSED>
 __device__ __forceinline__ void grad_finish(const GradC &gc, const TomoGeomC &g, int ixc, int iz, bool valid, double val, const double s0[3],
                                             const double s1[3], float *__restrict__ proj, float *__restrict__ grad, const float *__restrict__ bvec,
-                                            float *__restrict__ resid, double *__restrict__ red, int row_order, int lane, int wv)
+                                            float *__restrict__ resid, double *__restrict__ red, int row_order, int lane, int wv, int ipl, int w)
 {
     const double s[3] = {gc.s00[0] + ixc * gc.sdx, gc.s00[1], gc.s00[2] + iz * gc.sdz};
     double qv[3], gk[6];
@@ -73,14 +81,37 @@ __device__ __forceinline__ void grad_finish(const GradC &gc, const TomoGeomC &g,
         __shared__ double sh[4][7];
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
-            const double w = wave_sum_d(part[k]);
-            if (lane == 0) sh[wv][k] = w;
+            const double ws = wave_sum_d(part[k]);
+            if (lane == 0) sh[wv][k] = ws;
         }
         __syncthreads();
         if (threadIdx.x < 7) {
             const int k = threadIdx.x;
-            atomicAdd(&red[(size_t)gc.slot * 7 + k], sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k]);
+            const size_t n_wg = (size_t)grad_wg_per_proj(g);
+            red[((size_t)ipl * 7 + k) * n_wg + (size_t)w] = (sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]);
         }
+    }
+}
+
+// second stage of the fused reduction: one work-group per projection of the launch adds the n_wg partials of each of the seven sums in
+// a FIXED order (thread t takes w = t, t + 256, ... in ascending order, then a fixed LDS tree) and stores them at the caller's slot.
+__global__ __launch_bounds__(256) void k_cost_grad_reduce(const GradC *__restrict__ gcs, const double *__restrict__ part, double *__restrict__ red, int n_wg)
+{
+    __shared__ double sh[256];
+    const int ipl = blockIdx.x, t = threadIdx.x;
+    const int slot = gcs[ipl].slot;
+    for (int k = 0; k < 7; ++k) {
+        const double *p = part + ((size_t)ipl * 7 + k) * (size_t)n_wg;
+        double acc = 0.0;
+        for (int w = t; w < n_wg; w += 256) acc += p[w];
+        sh[t] = acc;
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) {
+            if (t < h) sh[t] += sh[t + h];
+            __syncthreads();
+        }
+        if (t == 0) red[(size_t)slot * 7 + k] = sh[0];
+        __syncthreads();
     }
 }
 
@@ -175,7 +206,8 @@ __global__ __launch_bounds__(256) void k_proj_grad(const ProjC *__restrict__ pcs
         s0[0] += (double)a0x; s0[1] += (double)a0y; s0[2] += (double)a0z;
         s1[0] += (double)a1x; s1[1] += (double)a1y; s1[2] += (double)a1z;
     }
-    grad_finish<FUSED>(gc, g, ixc, iz, valid, val, s0, s1, proj, grad, bvec, resid, red, row_order, lane, wv);
+    grad_finish<FUSED>(gc, g, ixc, iz, valid, val, s0, s1, proj, grad, bvec, resid, red, row_order, lane, wv, ip,
+                       (int)blockIdx.y * ((g.ndz + 63) / 64) + (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -203,13 +235,15 @@ __global__ __launch_bounds__(256, GRAD_MIN_WG) void k_proj_grad_v2(const ProjC *
     // instead of the whole volume streaming from HBM once per projection.  Workgroups are dealt to the 8 XCDs round-robin
     // in dispatch order, so the swizzle gives each XCD a contiguous range of ix groups (neighbouring rays share L2 lines).
     // (Volumes that fit the cache anyway keep the plain order row_order < 16: z chunk fastest, projection slowest.)
-    int ix, ip, iz;
+    int ix, ip, iz, wg;                               // wg: this work-group's index inside its projection = x group * z chunks + z chunk
     if (row_order & 16) {
         const int nxg = gridDim.x;
         const int xg = ((nxg & 7) == 0) ? ((int)(blockIdx.x & 7) * (nxg >> 3) + (int)(blockIdx.x >> 3)) : (int)blockIdx.x;
         ix = xg * 4 + wv, ip = blockIdx.y, iz = blockIdx.z * 64 + lane;
+        wg = xg * (int)gridDim.z + (int)blockIdx.z;
     } else {
         ix = blockIdx.y * 4 + wv, ip = blockIdx.z, iz = blockIdx.x * 64 + lane;
+        wg = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
     }
     row_order &= 15;
     const bool valid = (ix < g.ndx) && (iz < g.ndz);
@@ -314,7 +348,7 @@ __global__ __launch_bounds__(256, GRAD_MIN_WG) void k_proj_grad_v2(const ProjC *
         s0[0] += (double)a0xy.x; s0[1] += (double)a0xy.y; s0[2] += (double)az.x;
         s1[0] += (double)a1xy.x; s1[1] += (double)a1xy.y; s1[2] += (double)az.y;
     }
-    grad_finish<FUSED>(gc, g, ixc, iz, valid, val, s0, s1, proj, grad, bvec, resid, red, row_order, lane, wv);
+    grad_finish<FUSED>(gc, g, ixc, iz, valid, val, s0, s1, proj, grad, bvec, resid, red, row_order, lane, wv, ip, wg);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -344,13 +378,15 @@ __global__ __launch_bounds__(256, GRAD_MIN_WG) void k_proj_grad_v3(const ProjC *
 {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int ix, ip, iz;
+    int ix, ip, iz, wg;
     if (row_order & 16) {                              // cache-ordered grid, see k_proj_grad_v2
         const int nxg = gridDim.x;
         const int xg = ((nxg & 7) == 0) ? ((int)(blockIdx.x & 7) * (nxg >> 3) + (int)(blockIdx.x >> 3)) : (int)blockIdx.x;
         ix = xg * 4 + wv, ip = blockIdx.y, iz = blockIdx.z * 64 + lane;
+        wg = xg * (int)gridDim.z + (int)blockIdx.z;
     } else {
         ix = blockIdx.y * 4 + wv, ip = blockIdx.z, iz = blockIdx.x * 64 + lane;
+        wg = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
     }
     row_order &= 15;
     const bool valid = (ix < g.ndx) && (iz < g.ndz);
@@ -486,7 +522,7 @@ __global__ __launch_bounds__(256, GRAD_MIN_WG) void k_proj_grad_v3(const ProjC *
         s0[0] += (double)a0x; s0[1] += (double)a0y; s0[2] += (double)a0z;
         s1[0] += (double)a1x; s1[1] += (double)a1y; s1[2] += (double)a1z;
     }
-    grad_finish<FUSED>(gc, g, ixc, iz, valid, val, s0, s1, proj, grad, bvec, resid, red, row_order, lane, wv);
+    grad_finish<FUSED>(gc, g, ixc, iz, valid, val, s0, s1, proj, grad, bvec, resid, red, row_order, lane, wv, ip, wg);
 }
 
 

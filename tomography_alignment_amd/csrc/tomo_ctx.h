@@ -54,6 +54,10 @@ struct tomo_ctx {
     double *d_red = nullptr;
     double *h_red = nullptr;
     size_t red_cap = 0;     // doubles
+    // work-group partial sums of the fused cost / gradient kernels (tomo_cost_grad_rows: added in a fixed order, no atomics); grow-only,
+    // handed back by tomo_release_workspace
+    double *d_red_part = nullptr;
+    size_t red_part_cap = 0;     // doubles
     // TOMO_N_ACC double accumulators (tomo_acc_zero / tomo_vec_dot_acc / tomo_acc_fetch) + their pinned host mirror
     double *d_acc = nullptr;
     double *h_acc = nullptr;
@@ -105,6 +109,7 @@ struct tomo_ctx {
 int tomo_fail(tomo_ctx *ctx, int code, const std::string &msg);
 int tomo_ensure_stage(tomo_ctx *ctx, size_t bytes);
 int tomo_ensure_red(tomo_ctx *ctx, size_t n_doubles);
+int tomo_ensure_red_part(tomo_ctx *ctx, size_t n_doubles);
 int tomo_ensure_ws(tomo_ctx *ctx, size_t n_floats);
 int tomo_ensure_blk(tomo_ctx *ctx, size_t n_ints);
 void tomo_csr_release(tomo_ctx *ctx);

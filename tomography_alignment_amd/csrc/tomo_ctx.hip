@@ -65,6 +65,7 @@ extern "C" int tomo_ctx_destroy(tomo_ctx *c)
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_red) (void)hipFree(c->d_red);
     if (c->h_red) (void)hipHostFree(c->h_red);
+    if (c->d_red_part) (void)hipFree(c->d_red_part);
     if (c->d_acc) (void)hipFree(c->d_acc);
     if (c->h_acc) (void)hipHostFree(c->h_acc);
     if (c->d_ws) (void)hipFree(c->d_ws);
@@ -219,6 +220,18 @@ int tomo_ensure_red(tomo_ctx *ctx, size_t n)
     return TOMO_OK;
 }
 
+int tomo_ensure_red_part(tomo_ctx *ctx, size_t n)
+{
+    if (n <= ctx->red_part_cap) return TOMO_OK;
+    TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_red_part) (void)hipFree(ctx->d_red_part);
+    ctx->d_red_part = nullptr;
+    ctx->red_part_cap = 0;
+    TOMO_HIP(ctx, hipMalloc((void **)&ctx->d_red_part, n * sizeof(double)));
+    ctx->red_part_cap = n;
+    return TOMO_OK;
+}
+
 // The grow-only workspaces a context keeps between calls can be large (the TV-FISTA proximal step holds 7 volumes: 28 GB at 1024^3):
 // a long-lived context hands them back with this.  The next call that needs one allocates it again.
 extern "C" int tomo_release_workspace(tomo_ctx *ctx)
@@ -229,6 +242,9 @@ extern "C" int tomo_release_workspace(tomo_ctx *ctx)
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     ctx->d_ws = nullptr;
     ctx->ws_elems = 0;
+    if (ctx->d_red_part) (void)hipFree(ctx->d_red_part);
+    ctx->d_red_part = nullptr;
+    ctx->red_part_cap = 0;
     return TOMO_OK;
 }
 

@@ -93,6 +93,7 @@ static inline dim3 grad_grid(const TomoGeomC &g, int n_proj)
 }
 
 #define TOMO_MAX_GRID_Z 65535
+#define TOMO_RED_PART_BYTES ((size_t)512 << 20)
 
 static bool invert3(const double m[3][3], double inv[3][3], double *det_out)
 {
@@ -596,29 +597,41 @@ extern "C" int tomo_cost_grad_rows(tomo_ctx *ctx, const double *h_poses, int n, 
     if (rc) return rc;
     rc = tomo_ensure_red(ctx, (size_t)n * 7 + 8);
     if (rc) return rc;
+    // the work-groups' partial sums (7 float64 each), added in a fixed order by k_cost_grad_reduce: at most TOMO_RED_PART_BYTES of them at
+    // a time (512^2 detector: 56 KB per pose; 1024^2: 224 KB), larger batches go through in several launches
+    const int n_wg = grad_wg_per_proj(g);
+    const size_t per_pose = (size_t)n_wg * 7;
+    const int max_poses = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, (TOMO_RED_PART_BYTES / sizeof(double)) / per_pose));
+    rc = tomo_ensure_red_part(ctx, per_pose * (size_t)max_poses);
+    if (rc) return rc;
     ProjC *d_pc = nullptr;
     GradC *d_gc = nullptr;
     int n_plain = 0;                                      // staged order: [near-untilted poses ..., tilted poses ...]
     rc = upload_projc(ctx, h_poses, n, true, &d_pc, &d_gc, h_rows, &n_plain);
     if (rc) return rc;
-    TOMO_HIP(ctx, hipMemsetAsync(ctx->d_red, 0, sizeof(double) * (size_t)n * 7, ctx->stream));
-    // up to two launches: the first group with one kernel variant, the second with another (grad_variant 4: v2 / v3 by tilt)
+    // up to two groups: the first with one kernel variant, the second with another (grad_variant 4: v2 / v3 by tilt)
     const int var_a = ctx->wide_rows ? 1 : ctx->grad_variant == 4 ? 2 : ctx->grad_variant;
     const int var_b = ctx->wide_rows ? 1 : ctx->grad_variant == 4 ? 3 : ctx->grad_variant;
     for (int part = 0; part < 2; ++part) {
-        const int first = part == 0 ? 0 : n_plain, cnt = part == 0 ? n_plain : n - n_plain, variant = part == 0 ? var_a : var_b;
-        if (cnt == 0) continue;
-        const ProjC *pc = d_pc + first;
-        const GradC *gc = d_gc + first;
-        if (variant == 1)
-            TOMO_LAUNCH(ctx, "k_cost_grad(v1)", k_proj_grad<true>, ray_grid(g, cnt), dim3(256), 0, pc, gc, ctx->d_volpad, (float *)nullptr,
-                        (float *)nullptr, d_b, d_resid, ctx->d_red, g, 0);
-        else if (variant == 2)
-            TOMO_LAUNCH(ctx, "k_cost_grad(v2)", k_proj_grad_v2<true>, grad_grid(g, cnt), dim3(256), 0, pc, gc, ctx->d_volpad, (float *)nullptr,
-                        (float *)nullptr, d_b, d_resid, ctx->d_red, g, grad_zslow(g, cnt) ? 16 : 0);
-        else
-            TOMO_LAUNCH(ctx, "k_cost_grad(v3)", k_proj_grad_v3<true>, grad_grid(g, cnt), dim3(256), 0, pc, gc, ctx->d_volpad, (float *)nullptr,
-                        (float *)nullptr, d_b, d_resid, ctx->d_red, g, grad_zslow(g, cnt) ? 16 : 0);
+        const int gfirst = part == 0 ? 0 : n_plain, gcnt = part == 0 ? n_plain : n - n_plain, variant = part == 0 ? var_a : var_b;
+        for (int first = gfirst; first < gfirst + gcnt; first += max_poses) {
+            const int cnt = std::min(max_poses, gfirst + gcnt - first);
+            const ProjC *pc = d_pc + first;
+            const GradC *gc = d_gc + first;
+            // block order by the size of the GROUP, not of this launch: the per-ray arithmetic does not depend on it, the cache behaviour does
+            const bool zslow = grad_zslow(g, gcnt) && cnt > 1;
+            const dim3 gg = zslow ? dim3((g.ndx + 3) / 4, cnt, (g.ndz + 63) / 64) : ray_grid(g, cnt);
+            if (variant == 1)
+                TOMO_LAUNCH(ctx, "k_cost_grad(v1)", k_proj_grad<true>, ray_grid(g, cnt), dim3(256), 0, pc, gc, ctx->d_volpad, (float *)nullptr,
+                            (float *)nullptr, d_b, d_resid, ctx->d_red_part, g, 0);
+            else if (variant == 2)
+                TOMO_LAUNCH(ctx, "k_cost_grad(v2)", k_proj_grad_v2<true>, gg, dim3(256), 0, pc, gc, ctx->d_volpad, (float *)nullptr,
+                            (float *)nullptr, d_b, d_resid, ctx->d_red_part, g, zslow ? 16 : 0);
+            else
+                TOMO_LAUNCH(ctx, "k_cost_grad(v3)", k_proj_grad_v3<true>, gg, dim3(256), 0, pc, gc, ctx->d_volpad, (float *)nullptr,
+                            (float *)nullptr, d_b, d_resid, ctx->d_red_part, g, zslow ? 16 : 0);
+            TOMO_LAUNCH(ctx, "k_cost_grad_reduce", k_cost_grad_reduce, dim3(cnt), dim3(256), 0, gc, (const double *)ctx->d_red_part, ctx->d_red, n_wg);
+        }
     }
     TOMO_HIP(ctx, hipMemcpyAsync(ctx->h_red, ctx->d_red, sizeof(double) * (size_t)n * 7, hipMemcpyDeviceToHost, ctx->stream));
     TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
