@@ -835,14 +835,13 @@ def align_rigid_e2e(comm, ctx, rank, world, sharded, N=512, n_proj=720, sirt_ite
     ctx.profile_enable(True)
     t0 = time.perf_counter()
     trace = []
-    _, a_rec, b_rec, xyz_rec, hist = align_rigid.run(data, n_outer=n_outer, sirt_iters=sirt_iters, bounds=((-6., 6.), (-6., 6.), (-0.05, 0.05), (-0.05, 0.05)),
-                                                     verbose=False, backend=be, align_kwargs={"trace": trace}, comm=comm if sharded else None,
-                                                     kernel_names=names, download=False)
+    _, a_rec, b_rec, xyz_rec, hist, loop = align_rigid.run(data, n_outer=n_outer, sirt_iters=sirt_iters, bounds=((-6., 6.), (-6., 6.), (-0.05, 0.05), (-0.05, 0.05)),
+                                                           verbose=False, backend=be, align_kwargs={"trace": trace}, comm=comm if sharded else None,
+                                                           kernel_names=names, download=False, return_loop=True)
     ctx.sync()
     comm.barrier()
     wall = comm.allreduce_max(time.perf_counter() - t0)
     ctx.profile_enable(False)
-    loop = align_rigid.run.last_loop
     # The kernel rate the LAST pass could have had: the very evaluations it made (same volume -- the pass ran against the reconstruction
     # still in HBM --, same poses, same measured rows), replayed in launches of a rank's whole block.  alignment_gradient.evals_per_sec is
     # taken on another pose population (all 0.5 deg from the truth); the optimisers' own points run from untilted starts to tilts on

@@ -121,9 +121,13 @@ TOMO_API int tomo_sync(tomo_ctx *ctx);
  * (entry points that need a geometry also do it themselves).  One context must still not be used by two threads at the same time. */
 TOMO_API int tomo_ctx_make_current(tomo_ctx *ctx);
 TOMO_API int tomo_set_option(tomo_ctx *ctx, const char *key, int value);
-/* Restrict the context's compute stream to a subset of the CUs (bit i of the mask = CU i in the HIP runtime's numbering; n_words 32-bit
- * words; n_words = 0 restores an unrestricted stream).  Work queued on the old stream is waited for.  Two contexts with disjoint masks run
- * their kernels side by side for certain; without masks the second kernel's work-groups queue behind the first's (tools/overlap_probe.py). */
+/* Restrict the context's compute stream to a subset of the CUs (hipExtStreamCreateWithCUMask: bit i of the mask = CU i in the HIP
+ * runtime's numbering; n_words 32-bit words; n_words = 0 restores the unrestricted stream; an all-zero mask is refused).  Work queued on
+ * the old stream is waited for.  AS MEASURED on this runtime (tools/overlap_probe.py, profiles/round5_overlap_probe.md): masks that are
+ * LEADING RANGES of the CUs ("the first k") restrict the stream and two contexts with disjoint ranges ran their kernels side by side;
+ * masks that keep some CUs of every group of 8 had no effect.  The masked stream is created with default flags, i.e. it is a BLOCKING
+ * stream: unlike the context's normal compute stream (hipStreamNonBlocking) it synchronises implicitly with the NULL stream.  A
+ * measurement aid (one-GPU overlap probes), not used by the solvers. */
 TOMO_API int tomo_ctx_set_cu_mask(tomo_ctx *ctx, const uint32_t *mask, int n_words);
 
 /* Geometry: replaces passing a `Geometry` object to utilities/ray_voxel_utilities.py:53,113.

@@ -137,12 +137,12 @@ def align_rigid_stages(ctx, comm, out):
     mine = np.array_split(np.arange(n_proj), comm.size)[comm.rank]
     shard_be = lambda: HipBackend(sirt_mpi.SIRT._shard_geometry(geo, mine), ctx=ctx)      # noqa: E731
     comm.force_pipeline = True            # the slab pipeline (reduce-scatter / own piece / all-gather) also at world 1
-    rec, a, bb, t, hist = align_rigid.run(data, n_outer=2, sirt_iters=8, verbose=False, backend=shard_be(), comm=comm)
+    rec, a, bb, t, hist, last_loop = align_rigid.run(data, n_outer=2, sirt_iters=8, verbose=False, backend=shard_be(), comm=comm, return_loop=True)
     out["e_rec"], out["e_a"], out["e_b"], out["e_xyz"] = rec, a, bb, t
     out["e_rmse"], out["e_shift_err"] = np.array([h["rmse"] for h in hist]), np.array([h["shift_err_px"] for h in hist])
     out["e_injected"] = np.abs(xyz[:, [0, 2]]).mean()
     out["e_spread"] = max(comm.allreduce_max(float(v)) + comm.allreduce_max(-float(v)) for v in np.concatenate([a, bb, t.ravel()]))
-    out["e_pipelined"] = bool(align_rigid.run.last_loop.solver._iter_pipelined)
+    out["e_pipelined"] = bool(last_loop.solver._iter_pipelined)
     ref = align_rigid.OuterLoop(data, backend=HipBackend(geo, ctx=ctx), comm=SingleComm())
     shd = align_rigid.OuterLoop(data, backend=shard_be(), comm=comm)
     for stage in (0, 1):

@@ -19,15 +19,22 @@ def _free_port():
     return p
 
 
-def _run(world, out):
+def _run(world, out, worker="_gloo_worker.py"):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
                    OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py"), out], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", worker), out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    logs = []
+    try:
+        for p in procs:
+            logs.append(p.communicate(timeout=600)[0].decode())
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                      # exactly the processes started here
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log
     return np.load(out)
@@ -118,6 +125,45 @@ def test_align_rigid_outer_loop_sharded_matches_unsharded(tmp_path):
     assert int(one["e_uploaded_rows"]) == 6 + 16 and int(two["e_uploaded_rows"]) == 3 + 16 and int(three["e_uploaded_rows"]) == 2 + 16
     injected = np.abs(one["e_true"][:, :2]).mean()
     assert one["e_shift_err"][-1] < one["e_shift_err"][0] < 0.7 * injected and one["e_rmse"][-1] < one["e_rmse"][0]
+
+
+@pytest.mark.timeout(900)
+def test_world_8_sirt_cgls_and_outer_loop(tmp_path):
+    """BASELINE configs 4 / 5 run on 8 GPUs; no box of this pool has more than one.  The bookkeeping an 8-rank run
+    depends on, at world 8 over gloo on the CPU (tests/_gloo_worker8.py; world 1 of the same program is the reference):
+      * angle blocks of unequal size -- 20 angles as 3 3 3 3 2 2 2 2, 10 projections as 2 2 1 1 1 1 1 1 (config 5's 720 split into 90-pose blocks);
+      * the slab plan with 8 slabs, each cut into 8 pieces, slabs 0 and 7 with left-over voxels (1 and 4) that go through the small all-reduce;
+      * SIRT and CGLS, pipelined, equal to the one-rank run at 1e-5; the collective counts per iteration; the same counts on every rank;
+      * one outer iteration of examples/align_rigid.run(comm=): every rank ends with the same pose table, each half equals the unsharded loop's,
+        a rank uploads only its own measured rows."""
+    one = _run(1, str(tmp_path / "h1.npz"), "_gloo_worker8.py")
+    eight = _run(8, str(tmp_path / "h8.npz"), "_gloo_worker8.py")
+    assert list(eight["block_sizes"]) == [3, 3, 3, 3, 2, 2, 2, 2] and list(one["block_sizes"]) == [20]
+    assert [np.array_split(np.arange(720), 8)[r].size for r in range(8)] == [90] * 8 and [np.array_split(np.arange(1024), 8)[r].size for r in range(8)] == [128] * 8
+    # the slab plan: 8 slabs of 15, 16 x 6 and 12 x planes, together the volume
+    px = eight["plan_x"]
+    assert px.shape == (8, 2) and px[0, 0] == 0 and px[-1, 1] == 123 and np.array_equal(px[1:, 0], px[:-1, 1]) and list(px[:, 1] - px[:, 0]) == [15] + [16] * 6 + [12]
+    n_it = 3
+    assert bool(eight["sirt_pipelined"]) and bool(one["sirt_pipelined"]) and bool(eight["cgls_pipelined"])
+    # first iteration's collectives in issue order: per slab a reduce-scatter of 8 pieces, then the left-over all-reduce where there is one
+    assert list(eight["slab_sizes"][:10]) == [3824, 1, 4080, 4080, 4080, 4080, 4080, 4080, 3056, 4], eight["slab_sizes"]
+    # counts [volume all-reduces, small (left-over) all-reduces, reduce-scatters, all-gathers, waits, gather waits]:
+    # init: V by one whole-volume all-reduce (recon/sirt_mpi.py:68); per iteration 8 reduce-scatters + 8 all-gathers + 2 left-overs, each waited for once
+    assert list(eight["sirt_init_counts"][:4]) == [1, 0, 0, 0]
+    assert list(eight["sirt_counts"]) == [0, 2 * n_it, 8 * n_it, 8 * n_it, 10 * n_it, 8 * n_it], eight["sirt_counts"]
+    assert list(one["sirt_counts"])[:4] == [0, 0, 8 * n_it, 8 * n_it]                 # one rank: a slab is one piece, nothing left over
+    assert list(eight["cgls_counts"][:4]) == [0, 2 * n_it, 8 * n_it, 8 * n_it], eight["cgls_counts"]
+    assert rel_max(eight["sirt_rec"], one["sirt_rec"]) < 1e-5 and np.allclose(eight["sirt_err"], one["sirt_err"], rtol=1e-5)
+    assert rel_max(eight["cgls_rec"], one["cgls_rec"]) < 1e-5 and np.allclose(eight["cgls_err"], one["cgls_err"], rtol=1e-5)
+    assert one["sirt_err"][-1] < one["sirt_err"][0] and one["cgls_err"][-1] < one["cgls_err"][0]
+    assert not np.any(eight["counts_spread"]), eight["counts_spread"]                 # every rank issued the same collectives
+    # the outer loop: same table everywhere, halves equal to the unsharded loop's, uploads = own rows (2 for rank 0) + the 16 ground-truth planes
+    for w in (one, eight):
+        assert float(w["e_spread"]) == 0.0 and float(w["st_sirt_rec"]) < 1e-5 and float(w["st_sirt_err"]) < 1e-5
+        assert float(w["st_align_x"]) < 1e-12 and int(w["st_align_nfev"]) == 0
+    assert int(eight["e_uploaded_rows"]) == 2 + 16 and int(one["e_uploaded_rows"]) == 10 + 16
+    assert abs(eight["e_rmse"][0] / one["e_rmse"][0] - 1) < 1e-5 and np.max(np.abs(eight["e_xyz"] - one["e_xyz"])) < 0.2
+    assert eight["e_shift_err"][-1] < 0.7 * np.abs(eight["e_true"][:, :2]).mean()
 
 
 def test_angle_split_is_the_reference_split():

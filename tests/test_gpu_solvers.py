@@ -361,6 +361,10 @@ def test_stream_overlap_waits_have_teeth(capsys):
     assert out["solvers_ok"], [c for c in out["cases"] if c[4] == "poisoned"]
     assert out["mutation_ok"], [c for c in out["cases"] if c[4] != "poisoned"]
     assert r.returncode == 0
+    if not out["control_raced"]:
+        # the un-waited control read never caught the doubled buffer in four attempts of growing idle time (a wall-clock race): the
+        # solver and mutation assertions above are the hard ones -- a dropped wait DID change the results in this very process
+        pytest.xfail("overlap control: could not race on this box (%s); solvers and mutation cases passed" % out["control_attempts"])
 
 
 def test_volume_residency_is_explicit(shepp32):

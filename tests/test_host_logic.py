@@ -443,6 +443,9 @@ def test_bench_launcher_and_roofline_logic_without_a_gpu(tmp_path, monkeypatch):
         pytest.skip("a GPU is present")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode == 2 and "2 GPUs requested, 0 visible" in out.stderr and out.stdout.strip() == ""
+    # the command the driver's scaling run uses for its largest point: the launcher must get as far as counting GPUs
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 2 and "8 GPUs requested, 0 visible" in out.stderr and out.stdout.strip() == ""
     import bench
     prof = tmp_path / "profiles"
     prof.mkdir()

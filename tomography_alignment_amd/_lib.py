@@ -216,11 +216,14 @@ class Context(object):
         self.check(self.lib.tomo_set_option(self.handle, key.encode(), int(value)))
 
     def set_cu_mask(self, cus=None):
-        """Restrict the compute stream to the CUs in `cus` (an iterable of CU indices; None: unrestricted)."""
+        """Restrict the compute stream to the CUs in `cus` (an iterable of CU indices; None: unrestricted).  As measured on this runtime only
+        LEADING RANGES (range(k)) take effect, and the masked stream is a blocking one (include/tomo.h: tomo_ctx_set_cu_mask)."""
         if cus is None:
             self.check(self.lib.tomo_ctx_set_cu_mask(self.handle, None, 0))
             return
         cus = sorted(set(int(c) for c in cus))
+        if not cus or cus[0] < 0:
+            raise ValueError("set_cu_mask: give at least one CU index >= 0 (None restores the unrestricted stream)")
         words = (max(cus) // 32 + 1) if cus else 1
         m = (ctypes.c_uint32 * words)()
         for c in cus:
@@ -340,18 +343,23 @@ class DeviceArray(object):
             pass
 
 
+KERNEL_SOURCE_FILES = ("Makefile", "kernels_grad.hip.h", "kernels_ray.hip.h", "kernels_tile.hip.h", "kernels_tile_flat.hip.h", "kernels_tile_gather.hip.h",
+                       "tomo_ctx.h", "tomo_project.hip", "tomo_raycore.h")
+
+
 def kernel_source_hash():
-    """sha256 (first 16 hex digits) over the HIP sources libtomo_hip.so is built from (csrc/*.hip, *.hip.h, *.h, Makefile), in name
-    order.  The committed PMC counters (profiles/sq_counters.json, profiles/pmc_traffic.json) carry the hash of the sources they were
-    taken on; bench.py refuses them when the kernels have changed since (counts of an old kernel must never be
-    divided by the time of a new one)."""
-    import glob
+    """sha256 (first 16 hex digits) over the sources of the projector and gradient kernels and of the code that configures and launches them
+    (KERNEL_SOURCE_FILES in csrc/: the kernel headers, tomo_raycore.h, tomo_project.hip, the context layout, the build flags), in name order.
+    The committed PMC counters (profiles/sq_counters.json, profiles/pmc_traffic.json) hold exactly those kernels and carry the hash of the
+    sources they were taken on; bench.py refuses them when these have changed since (counts of an old kernel must never be
+    divided by the time of a new one).  Round 6: the files that define none of those kernels (tomo_ctx.hip: context, vector lines,
+    collectives; tomo_f2py.hip, tomo_csr.hip, tomo_reg.hip) are no longer part of it -- an edit there does not make the counters stale."""
     import hashlib
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + [os.path.join(d, "Makefile")]):
-        h.update(os.path.basename(f).encode() + b"\0")
-        h.update(open(f, "rb").read())
+    for name in sorted(KERNEL_SOURCE_FILES):
+        h.update(name.encode() + b"\0")
+        h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -154,6 +154,11 @@ extern "C" int tomo_ctx_make_current(tomo_ctx *ctx)
 extern "C" int tomo_ctx_set_cu_mask(tomo_ctx *ctx, const uint32_t *mask, int n_words)
 {
     if (!ctx || n_words < 0 || (n_words > 0 && !mask)) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_ctx_set_cu_mask: bad args");
+    if (n_words > 0) {
+        bool any = false;
+        for (int i = 0; i < n_words; ++i) any |= mask[i] != 0;
+        if (!any) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_ctx_set_cu_mask: empty mask (n_words = 0 restores the unrestricted stream)");
+    }
     TOMO_HIP(ctx, hipSetDevice(ctx->device));
     TOMO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hipStream_t s = nullptr;
@@ -849,10 +854,17 @@ extern "C" int tomo_comm_join(tomo_ctx *ctx)
 // ---- device accumulators (include/tomo.h: tomo_acc_*): scalars of a solver iteration with one host synchronisation
 static int acc_ensure(tomo_ctx *ctx)
 {
-    if (ctx->d_acc) return TOMO_OK;
-    TOMO_HIP(ctx, hipSetDevice(ctx->device));
+    TOMO_HIP(ctx, hipSetDevice(ctx->device));            // every tomo_acc_* entry point comes through here: HIP's current device is per thread
+    if (ctx->d_acc && ctx->h_acc) return TOMO_OK;
+    // both or neither: a failed second allocation must not leave a half-made pair that the next call takes for a whole one
+    if (ctx->d_acc) { (void)hipFree(ctx->d_acc); ctx->d_acc = nullptr; }
+    if (ctx->h_acc) { (void)hipHostFree(ctx->h_acc); ctx->h_acc = nullptr; }
     TOMO_HIP(ctx, hipMalloc((void **)&ctx->d_acc, TOMO_N_ACC * sizeof(double)));
-    TOMO_HIP(ctx, hipHostMalloc((void **)&ctx->h_acc, TOMO_N_ACC * sizeof(double), hipHostMallocDefault));
+    if (hipHostMalloc((void **)&ctx->h_acc, TOMO_N_ACC * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+        (void)hipFree(ctx->d_acc);
+        ctx->d_acc = ctx->h_acc = nullptr;
+        return tomo_fail(ctx, TOMO_ERR_HIP, "tomo_acc: no pinned host memory for the accumulators' mirror");
+    }
     TOMO_HIP(ctx, hipMemsetAsync(ctx->d_acc, 0, TOMO_N_ACC * sizeof(double), ctx->stream));
     return TOMO_OK;
 }
@@ -883,6 +895,8 @@ extern "C" int tomo_acc_fetch(tomo_ctx *ctx, int slot0, int n, int allreduce, do
     int rc = acc_ensure(ctx);
     if (rc) return rc;
     if (n == 0) return TOMO_OK;
+    // a sum over the ranks was asked for: without a communicator that is only right on one rank (as tomo_allreduce_sum_f32 rules)
+    if (allreduce && !ctx->comm && ctx->n_ranks > 1) return tomo_fail(ctx, TOMO_ERR_STATE, "tomo_acc_fetch: comm not initialised");
     if (allreduce && ctx->comm) {
         tomo_prof_begin(ctx, "allreduce_scalars");
         ncclResult_t r = ncclAllReduce(ctx->d_acc + slot0, ctx->d_acc + slot0, (size_t)n, ncclFloat64, ncclSum, ctx->comm, ctx->stream);

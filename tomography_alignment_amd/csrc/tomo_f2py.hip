@@ -11,7 +11,7 @@
 // The reference's utilities/ray_voxel_utilities.py:103,164 calls these with the (3, n_rays, n_points) sample tables it has built in
 // numpy; `tomography_alignment_amd/src/ray_wt_grad.py` exposes them under the f2py module's name and signatures, so that file binds
 // this library without an edit.  HOST arrays in the Fortran (column-major) layout f2py hands to the routines, float64 / int32 as the
-// reference's; the arithmetic is the reference's float64 arithmetic in the reference's order (unfused: __dmul_rn / __dadd_rn), one ray
+// reference's; the arithmetic is the reference's float64 arithmetic in the reference's order (unfused: d_mul / d_add below), one ray
 // per thread.  This is the compatibility surface, not the fast path: the tables are 36 bytes per sample (77 GB per projection at
 // 1024^3), which is what the lattice kernels of tomo_project.hip exist to avoid.
 #include <rocprim/device/device_radix_sort.hpp>
@@ -19,7 +19,22 @@
 
 #include "tomo_ctx.h"
 
+// The library is built with -ffp-contract=fast: the BACKEND then fuses any multiply with a following add (TargetOptions::AllowFPOpFusion),
+// whatever `#pragma clang fp contract(off)` or the instruction flags say, and this compiler's __fmul_rn / __dmul_rn / __fadd_rn are plain
+// `x * y` / `x + y` (__clang_hip_math.h without OCML_BASIC_ROUNDED_OPERATIONS).  This file restates the reference's UNFUSED Fortran
+// arithmetic operation by operation (the f2py modules' bits are the test: tests/golden/g13), so every product passes through an empty asm
+// that the combiner cannot see through: one IEEE multiplication, then one IEEE addition.  (Checked in the ISA: no v_fma / v_fmac in this file's
+// kernels.)
+#pragma clang fp contract(off)
+
 namespace {
+
+__device__ __forceinline__ float f_mul(float a, float b) { float p = a * b; asm volatile("" : "+v"(p)); return p; }
+__device__ __forceinline__ float f_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float f_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ double d_mul(double a, double b) { double p = a * b; asm volatile("" : "+v"(p)); return p; }
+__device__ __forceinline__ double d_add(double a, double b) { return a + b; }
+__device__ __forceinline__ double d_sub(double a, double b) { return a - b; }
 
 // element (a, r, p) of a Fortran array of shape (3, n_rays, n_points)
 __device__ __forceinline__ size_t at3(int a, int r, int p, int n_rays) { return (size_t)a + 3u * ((size_t)r + (size_t)n_rays * p); }
@@ -31,7 +46,7 @@ __device__ __forceinline__ void corners_of(const int32_t *fp, const double *wf, 
 {
     const int fx = fp[at3(0, r, p, n_rays)], fy = fp[at3(1, r, p, n_rays)], fz = fp[at3(2, r, p, n_rays)];
     const double wfx = wf[at3(0, r, p, n_rays)], wfy = wf[at3(1, r, p, n_rays)], wfz = wf[at3(2, r, p, n_rays)];
-    const double wcx = __dsub_rn(1.0, wfx), wcy = __dsub_rn(1.0, wfy), wcz = __dsub_rn(1.0, wfz);
+    const double wcx = d_sub(1.0, wfx), wcy = d_sub(1.0, wfy), wcz = d_sub(1.0, wfz);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int ax = k >> 2, ay = (k >> 1) & 1, az = k & 1;
@@ -59,9 +74,9 @@ __global__ __launch_bounds__(64) void k_f2py_interp(const int32_t *__restrict__ 
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             g[0][a] = gt[0][a]; g[1][a] = gt[1][a]; g[2][a] = gt[2][a];
-            g[3][a] = __dadd_rn(gt[3][a], __dmul_rn(st, gt[6][a]));      // :139-141
-            g[4][a] = __dadd_rn(gt[4][a], __dmul_rn(st, gt[7][a]));
-            g[5][a] = __dadd_rn(gt[5][a], __dmul_rn(st, gt[8][a]));
+            g[3][a] = d_add(gt[3][a], d_mul(st, gt[6][a]));      // :139-141
+            g[4][a] = d_add(gt[4][a], d_mul(st, gt[7][a]));
+            g[5][a] = d_add(gt[5][a], d_mul(st, gt[8][a]));
         }
         Corner c[8];
         corners_of(fp, wf, r, p, n_rays, c);
@@ -69,15 +84,15 @@ __global__ __launch_bounds__(64) void k_f2py_interp(const int32_t *__restrict__ 
         for (int k = 0; k < 8; ++k) {
             if (c[k].x < 0 || c[k].x >= nx || c[k].y < 0 || c[k].y >= ny || c[k].z < 0 || c[k].z >= nz) continue;     // per corner  :142
             const double v = recon[((size_t)c[k].x * ny + c[k].y) * nz + c[k].z];
-            const double wt = __dmul_rn(__dmul_rn(c[k].wx, c[k].wy), c[k].wz);                                        // :144
-            img = __dadd_rn(img, __dmul_rn(v, wt));                                                                 // :145
+            const double wt = d_mul(d_mul(c[k].wx, c[k].wy), c[k].wz);                                        // :144
+            img = d_add(img, d_mul(v, wt));                                                                 // :145
             // g1 = -+ wy wz rec g(:,1) etc. (:146-148): the products are formed left to right as the Fortran writes them
-            const double a1 = __dmul_rn(__dmul_rn((c[k].sx < 0 ? -c[k].wy : c[k].wy), c[k].wz), v);
-            const double a2 = __dmul_rn(__dmul_rn((c[k].sy < 0 ? -c[k].wx : c[k].wx), c[k].wz), v);
-            const double a3 = __dmul_rn(__dmul_rn((c[k].sz < 0 ? -c[k].wx : c[k].wx), c[k].wy), v);
+            const double a1 = d_mul(d_mul((c[k].sx < 0 ? -c[k].wy : c[k].wy), c[k].wz), v);
+            const double a2 = d_mul(d_mul((c[k].sy < 0 ? -c[k].wx : c[k].wx), c[k].wz), v);
+            const double a3 = d_mul(d_mul((c[k].sz < 0 ? -c[k].wx : c[k].wx), c[k].wy), v);
 #pragma unroll
             for (int q = 0; q < 6; ++q)
-                gr[q] = __dadd_rn(gr[q], __dadd_rn(__dadd_rn(__dmul_rn(a1, g[q][0]), __dmul_rn(a2, g[q][1])), __dmul_rn(a3, g[q][2])));   // :149
+                gr[q] = d_add(gr[q], d_add(d_add(d_mul(a1, g[q][0]), d_mul(a2, g[q][1])), d_mul(a3, g[q][2])));   // :149
         }
     }
     det_img[r] = img;
@@ -103,7 +118,7 @@ __global__ __launch_bounds__(64) void k_f2py_sparse(const int32_t *__restrict__ 
             if (FILL) {
                 det[n] = r;                                                               // :37
                 dat[n] = (c[k].x * ny + c[k].y) * nz + c[k].z;                            // :38
-                wts[n] = __dmul_rn(__dmul_rn(c[k].wx, c[k].wy), c[k].wz);                 // :39
+                wts[n] = d_mul(d_mul(c[k].wx, c[k].wy), c[k].wz);                 // :39
             }
             ++n;
         }
@@ -192,7 +207,7 @@ extern "C" int tomo_trilinear_ray_sparse(tomo_ctx *ctx, const int32_t *h_floor_p
 //   1. k_vox_keys: entry e = 4 i + k (voxel i, corner k in the emission order (fx,fz), (fx+1,fz), (fx,fz+1), (fx+1,fz+1): :25-49) gets the key
 //      "pixel it lands on" (Fortran (ndim_z, ndim_x) storage: (fz-1) + ndim_z (fx-1)) or n_pix when the per-pixel bounds test fails;
 //   2. a STABLE radix sort of (key, e): entries of one pixel stay in ascending e = voxel order;
-//   3. k_vox_interp_ordered: one thread per pixel walks its run and adds with unfused single-precision operations (__fmul_rn / __fadd_rn,
+//   3. k_vox_interp_ordered: one thread per pixel walks its run and adds with unfused single-precision operations (f_mul / f_add,
 //      products left to right as the Fortran writes them).  tests/golden/g13 (the f2py module's own output): bit-identical.
 // bilinear_sparse is a stream compaction in voxel order: per-voxel counts -> exclusive scan -> fill.
 // ------------------------------------------------------------------------------------------------
@@ -237,20 +252,20 @@ __global__ __launch_bounds__(64) void k_vox_interp_ordered(uint32_t n_entries, c
         const size_t i = id >> 2;
         const int a = id & 1, b = (id >> 1) & 1;
         const float ax = alpha_x[i], az = alpha_z[i], v = rec[i];
-        const float omx = __fsub_rn(1.f, ax), omz = __fsub_rn(1.f, az);
+        const float omx = f_sub(1.f, ax), omz = f_sub(1.f, az);
         // det_img(..) + rec(i) * wx * wz, product left to right (:26,32,38,44)
-        img = __fadd_rn(img, __fmul_rn(__fmul_rn(v, a ? ax : omx), b ? az : omz));
+        img = f_add(img, f_mul(f_mul(v, a ? ax : omx), b ? az : omz));
         // g0 = g(:,1) * f0 * rec(i), g2 = g(:,3) * f2 * rec(i) with the factors as written at :27-28,33-34,39-40,45-46
         float f0, f2;
         if (!a && !b) { f0 = omz; f2 = omx; }
-        else if (a && !b) { f0 = __fmul_rn(-1.f, omz); f2 = ax; }
-        else if (!a && b) { f0 = az; f2 = __fmul_rn(-1.f, omx); }
-        else { f0 = __fmul_rn(-1.f, az); f2 = __fmul_rn(-1.f, ax); }
+        else if (a && !b) { f0 = f_mul(-1.f, omz); f2 = ax; }
+        else if (!a && b) { f0 = az; f2 = f_mul(-1.f, omx); }
+        else { f0 = f_mul(-1.f, az); f2 = f_mul(-1.f, ax); }
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-            const float g0 = __fmul_rn(__fmul_rn(der[(size_t)q + 18u * i], f0), v);            // der_points(q, 1, i), Fortran (6, 3, n_vox)
-            const float g2 = __fmul_rn(__fmul_rn(der[(size_t)q + 12u + 18u * i], f2), v);      // der_points(q, 3, i)
-            g[q] = __fadd_rn(g[q], __fadd_rn(g0, g2));
+            const float g0 = f_mul(f_mul(der[(size_t)q + 18u * i], f0), v);            // der_points(q, 1, i), Fortran (6, 3, n_vox)
+            const float g2 = f_mul(f_mul(der[(size_t)q + 12u + 18u * i], f2), v);      // der_points(q, 3, i)
+            g[q] = f_add(g[q], f_add(g0, g2));
         }
     }
     det_img[o] = img;
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(256) void k_vox_sparse_fill(int n_vox, const int32_
     if (i >= n_vox) return;
     const int64_t fx = floor_x[i], fz = floor_z[i];
     const float ax = alpha_x[i], az = alpha_z[i];
-    const float omx = __fsub_rn(1.f, ax), omz = __fsub_rn(1.f, az);
+    const float omx = f_sub(1.f, ax), omz = f_sub(1.f, az);
     int n = start[i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -275,7 +290,7 @@ __global__ __launch_bounds__(256) void k_vox_sparse_fill(int n_vox, const int32_
         if (!(x >= 0 && x < ndim_x && z >= 0 && z < ndim_z)) continue;
         dat[n] = i;                                                  // :82  (0-based for python)
         det[n] = (int32_t)(x + (int64_t)ndim_x * z);                 // :83  x-fastest
-        wts[n] = __fmul_rn(a ? ax : omx, b ? az : omz);              // :84,91,98,105
+        wts[n] = f_mul(a ? ax : omx, b ? az : omz);              // :84,91,98,105
         ++n;
     }
 }

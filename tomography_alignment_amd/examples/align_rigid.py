@@ -82,6 +82,7 @@ class OuterLoop(object):
         if self.d_rec is not None:
             opts["rec"] = self.d_rec                                          # in place, in HBM
         angles = np.array([self.phi, self.alpha_rec, self.beta_rec]).T
+        self.solver = None              # drop the previous solver's buffers BEFORE the next one allocates its own (d_rec is held separately)
         if self.comm is None:
             self.solver = sirt.SIRT(self.geom, self.d_b, angles, self.xyz_rec, options=opts)
         else:
@@ -116,10 +117,12 @@ class OuterLoop(object):
 
 
 def run(data, n_outer=5, sirt_iters=50, bounds=DEFAULT_BOUNDS, verbose=True, backend=None, align_kwargs=None, comm=None,
-        kernel_names=None, download=True):
+        kernel_names=None, download=True, return_loop=False):
     """The loop of examples/align_rigid.py:36-52 (see OuterLoop for `data` and `comm`).
     kernel_names   with a HIP context: the history carries the HIP-event kernel time of each half of each outer iteration for these names.
-    Returns (rec or None when not `download`, alpha, beta, xyz, history); `run.last_loop.d_rec` is the reconstruction in HBM."""
+    Returns (rec or None when not `download`, alpha, beta, xyz, history) -- with `return_loop` a sixth element, the OuterLoop itself
+    (`loop.d_rec`: the reconstruction where it lies in HBM, `loop.solver`, `loop.d_b`).  Nothing is kept alive behind the caller's back:
+    until round 5 the loop was parked in `run.last_loop`, which pinned about six volume-sized buffers until the next call."""
     loop = OuterLoop(data, backend=backend, comm=comm, kernel_names=kernel_names)
     ctx = loop.ctx
     history = []
@@ -144,12 +147,9 @@ def run(data, n_outer=5, sirt_iters=50, bounds=DEFAULT_BOUNDS, verbose=True, bac
         history.append(entry)
         if verbose and loop.rank == 0:
             print(entry)
-    run.last_loop = loop
     rec = loop.download() if (download and loop.d_rec is not None) else None
-    return rec, loop.alpha_rec, loop.beta_rec, loop.xyz_rec, history
-
-
-run.last_loop = None
+    out = (rec, loop.alpha_rec, loop.beta_rec, loop.xyz_rec, history)
+    return out + (loop,) if return_loop else out
 
 
 def _kernel_ms(ctx, names):

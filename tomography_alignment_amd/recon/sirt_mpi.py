@@ -126,15 +126,18 @@ class SIRT(SlabPipeline, _SIRT):
         if self.size == 1:
             return a
         a = np.asarray(a)
-        if a.size > 4096:
-            # volume-sized (the gradient of run_regularized_gradient_descent, every line-search evaluation): the float32 DEVICE collective --
-            # allreduce_array is the small-scalar path (float64 through a pinned staging buffer that only ever grows)
-            buf = self.be.upload(a.astype(np.float32, copy=False).ravel())
+        if a.dtype == np.float32 and a.size > 4096:
+            # volume-sized float32 (the gradient of run_regularized_gradient_descent in the default precision): the float32 DEVICE collective
+            buf = self.be.upload(a.ravel())
             self.comm.allreduce_sum_(buf)
-            return self.be.download(buf).reshape(a.shape).astype(a.dtype, copy=False)
-        out = np.array(a, np.float64)
-        self.comm.allreduce_array(out)
-        return out.astype(a.dtype, copy=False)
+            return self.be.download(buf).reshape(a.shape)
+        # everything else keeps float64 end to end, as the reference's MPI.DOUBLE Allreduce does for precision=np.float64
+        # (recon/sirt_mpi.py:159-162): allreduce_array is a float64 collective through a pinned staging buffer that only ever grows, so a
+        # large array goes through it in pieces of 1 M values (the arithmetic must not change with the array's size)
+        out = np.array(a, np.float64).ravel()
+        for lo in range(0, out.size, 1 << 20):
+            self.comm.allreduce_array(out[lo:lo + (1 << 20)])
+        return out.reshape(a.shape).astype(a.dtype, copy=False)
 
     def _is_root(self):
         return self.my_rank == 0
