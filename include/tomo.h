@@ -116,7 +116,14 @@ TOMO_API int tomo_sync(tomo_ctx *ctx);
  *                 sums -- shows which float32 step an error comes from (profiles/round4_grad_error_model.md); default 0
  *   "comm_test_poison_us" n (tests only): every asynchronous collective first doubles its buffer, idles n microseconds and halves it
  *                 again on the communication stream, so that a compute-stream kernel that did not wait for it is caught by a
- *                 one-rank run; default 0 */
+ *                 one-rank run; default 0
+ *   "comm_test_copy_eighths" k, "comm_test_copy_wgs" w (measurements only; tools/contention_probe.py): every asynchronous collective also copies
+ *                 k/8 of the buffer it touches to a scratch buffer on the communication stream -- by hipMemcpyAsync (w = 0) or by a copy kernel
+ *                 of w work-groups -- so that a one-rank run carries the HBM / CU load the collectives of an N-rank run would add; default 0
+ *   "roctx" 0 / 1 (process-wide; also TOMO_ROCTX=1 in the environment): roctx ranges named after the entry point around tomo_forward(_xslab),
+ *                 tomo_adjoint(_xslab), tomo_backproject_voxel, tomo_proj_grad, tomo_cost_grad(_rows) and the collectives, through
+ *                 librocprofiler-sdk-roctx.so / libroctx64.so loaded on demand (rocprofv3 --marker-trace); TOMO_ERR_UNSUPPORTED if neither loads;
+ *                 default 0 -- the reference has print timings only (recon/sirt.py:57,80-82) */
 /* HIP's current device is per thread: a thread other than the context's creator calls this once before it uses the context
  * (entry points that need a geometry also do it themselves).  One context must still not be used by two threads at the same time. */
 TOMO_API int tomo_ctx_make_current(tomo_ctx *ctx);

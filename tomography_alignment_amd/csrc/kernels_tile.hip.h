@@ -377,7 +377,14 @@ __global__ __launch_bounds__(NW * 64, TILE_MIN_WG) void k_tile(const AdjC *__res
                     const int64_t rb0 = c.fp0[0] + (int64_t)ix * c.fu[0] + (int64_t)jlo * c.fd[0] - org[0];
                     const int64_t rb1 = c.fp0[1] + (int64_t)ix * c.fu[1] + (int64_t)jlo * c.fd[1] - org[1];
                     const int64_t rb2 = c.fp0[2] + (int64_t)ix * c.fu[2] + (int64_t)jlo * c.fd[2] - org[2];
+                    // TOMO_ABLATE_TILE (timing experiments only, results are wrong by construction; profiles/round6_tilted_split.md): 1 = no sample
+                    // loop (what is left is staging / zeroing, the per-(tile, projection) and per-row set-up, the row's global atomic or sinogram
+                    // read, and the flushes); 2 = adjoint without the flushes; 3 = both
+#if defined(TOMO_ABLATE_TILE) && (TOMO_ABLATE_TILE & 1)
+                    const int cnt = 0;
+#else
                     const int cnt = jhi - jlo;
+#endif
                     for (int izb = iz_first; izb <= iz_last; izb += 64) {
                         const int iz = izb + lane;
                         const bool lane_ok = iz <= iz_last;
@@ -453,6 +460,9 @@ __global__ __launch_bounds__(NW * 64, TILE_MIN_WG) void k_tile(const AdjC *__res
         }
         if (FWD) break;
         __syncthreads();
+#if defined(TOMO_ABLATE_TILE) && (TOMO_ABLATE_TILE & 2)
+        continue;
+#endif
         // flush this batch: interior of the image is exclusively ours, the +1 faces are shared => global atomics
         for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += NW * 64) {
             const int v = acc[e];

@@ -54,6 +54,10 @@ struct tomo_ctx {
     double *d_red = nullptr;
     double *h_red = nullptr;
     size_t red_cap = 0;     // doubles
+    // measurement hook: synthetic copy traffic beside the asynchronous collectives (tomo_ctx.hip: comm_async)
+    int comm_test_copy_eighths = 0, comm_test_copy_wgs = 0;
+    void *d_comm_scratch = nullptr;
+    size_t comm_scratch_bytes = 0;
     // work-group partial sums of the fused cost / gradient kernels (tomo_cost_grad_rows: added in a fixed order, no atomics); grow-only,
     // handed back by tomo_release_workspace
     double *d_red_part = nullptr;
@@ -107,6 +111,18 @@ struct tomo_ctx {
 };
 
 int tomo_fail(tomo_ctx *ctx, int code, const std::string &msg);
+
+// roctx ranges around the C-ABI's projector / gradient / collective entry points (the reference has print timings only).  Off by
+// default and without a link-time dependency: TOMO_ROCTX=1 in the environment, or tomo_set_option(ctx, "roctx", 1), dlopens
+// librocprofiler-sdk-roctx.so (rocprofv3 --marker-trace) -- or libroctx64.so -- on first use; the ranges are named after the entry points.
+struct TomoRange {
+    bool on;
+    explicit TomoRange(const char *name);
+    ~TomoRange();
+    TomoRange(const TomoRange &) = delete;
+    TomoRange &operator=(const TomoRange &) = delete;
+};
+int tomo_roctx_enable(int on);      // 0 ok, -1: no roctx library could be loaded
 int tomo_ensure_stage(tomo_ctx *ctx, size_t bytes);
 int tomo_ensure_red(tomo_ctx *ctx, size_t n_doubles);
 int tomo_ensure_red_part(tomo_ctx *ctx, size_t n_doubles);

@@ -66,6 +66,7 @@ extern "C" int tomo_ctx_destroy(tomo_ctx *c)
     if (c->d_red) (void)hipFree(c->d_red);
     if (c->h_red) (void)hipHostFree(c->h_red);
     if (c->d_red_part) (void)hipFree(c->d_red_part);
+    if (c->d_comm_scratch) (void)hipFree(c->d_comm_scratch);
     if (c->d_acc) (void)hipFree(c->d_acc);
     if (c->h_acc) (void)hipHostFree(c->h_acc);
     if (c->d_ws) (void)hipFree(c->d_ws);
@@ -178,6 +179,8 @@ extern "C" int tomo_set_option(tomo_ctx *ctx, const char *key, int value)
     else if (!strcmp(key, "grad_variant")) ctx->grad_variant = value;
     else if (!strcmp(key, "grad_v1_prec")) ctx->grad_v1_prec = value & 3;
     else if (!strcmp(key, "comm_test_poison_us")) ctx->comm_test_poison_us = value;
+    else if (!strcmp(key, "comm_test_copy_eighths")) ctx->comm_test_copy_eighths = value < 0 ? 0 : value;
+    else if (!strcmp(key, "comm_test_copy_wgs")) ctx->comm_test_copy_wgs = value < 0 ? 0 : value;
     else if (!strcmp(key, "adj_flat_gather")) ctx->adj_flat_gather = value;
     else if (!strcmp(key, "fwd_flat_ztiles")) ctx->fwd_flat_ztiles = value;
     else if (!strcmp(key, "fwd_flat_wide")) {
@@ -190,6 +193,9 @@ extern "C" int tomo_set_option(tomo_ctx *ctx, const char *key, int value)
     else if (!strcmp(key, "fwd_flat_tab")) ctx->fwd_flat_tab = value;
     else if (!strcmp(key, "reuse_staged_volume")) ctx->reuse_staged = value;
     else if (!strcmp(key, "reuse_sino_flags")) ctx->reuse_sino_flags = value;
+    else if (!strcmp(key, "roctx")) {
+        if (tomo_roctx_enable(value)) return tomo_fail(ctx, TOMO_ERR_UNSUPPORTED, "roctx: neither librocprofiler-sdk-roctx.so nor libroctx64.so could be loaded");
+    }
     else return tomo_fail(ctx, TOMO_ERR_ARG, std::string("unknown option ") + key);
     return TOMO_OK;
 }
@@ -342,6 +348,44 @@ static hipEvent_t prof_event(tomo_ctx *ctx)
     (void)hipEventCreate(&e);
     return e;
 }
+
+// ---- roctx (see tomo_ctx.h): process-wide, loaded on demand
+#include <dlfcn.h>
+namespace {
+struct Roctx {
+    int state = 0;                  // 0 not tried, 1 on, -1 unavailable, 2 loaded but switched off
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+} g_roctx;
+bool roctx_load()
+{
+    for (const char *lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+        void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        g_roctx.push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+        g_roctx.pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (g_roctx.push && g_roctx.pop) return true;
+    }
+    return false;
+}
+bool roctx_on()
+{
+    if (g_roctx.state == 0) {
+        const char *e = getenv("TOMO_ROCTX");
+        g_roctx.state = (e && *e && *e != '0') ? (roctx_load() ? 1 : -1) : 2;
+    }
+    return g_roctx.state == 1;
+}
+}  // namespace
+int tomo_roctx_enable(int on)
+{
+    if (!on) { if (g_roctx.state == 1) g_roctx.state = 2; return 0; }
+    if (!g_roctx.push && !roctx_load()) { g_roctx.state = -1; return -1; }
+    g_roctx.state = 1;
+    return 0;
+}
+TomoRange::TomoRange(const char *name) : on(roctx_on()) { if (on) (void)g_roctx.push(name); }
+TomoRange::~TomoRange() { if (on) (void)g_roctx.pop(); }
 
 void tomo_prof_begin_on(tomo_ctx *ctx, const char *name, hipStream_t stream)
 {
@@ -739,6 +783,7 @@ extern "C" int tomo_comm_destroy(tomo_ctx *ctx)
 
 extern "C" int tomo_allreduce_sum_f32(tomo_ctx *ctx, float *d_buf, int64_t n)
 {
+    TomoRange roctx_range("tomo_allreduce_sum_f32");
     if (!ctx) return tomo_fail(ctx, TOMO_ERR_ARG, "null ctx");
     if (!ctx->comm) return ctx->n_ranks == 1 ? TOMO_OK : tomo_fail(ctx, TOMO_ERR_STATE, "comm not initialised");
     tomo_prof_begin(ctx, "allreduce_f32");
@@ -762,12 +807,25 @@ __global__ void k_comm_test_idle(long long ticks)      // one wave; wall_clock64
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 
+// Measurement hook (options comm_test_copy_eighths / comm_test_copy_wgs; tools/contention_probe.py, profiles/round6_contention_probe.md): on a
+// ONE-rank communicator the collectives move nothing, so the kernels of a rank's share have the chip to themselves -- unlike at P = 8, where
+// a ring reduce-scatter / all-gather of a slab reads and writes (P-1)/P of its bytes in this GPU's HBM through RCCL's own work-groups while
+// the back-projection of the next slab runs.  With comm_test_copy_eighths = k every asynchronous collective also copies k/8 of the buffer
+// it touches to a scratch buffer on the communication stream, inside its profile record: by hipMemcpyAsync (comm_test_copy_wgs = 0: the
+// copy engine / blit kernel at full rate) or by a copy kernel of comm_test_copy_wgs work-groups (RCCL-like: a fixed, small number of
+// work-groups that hold CUs and stream at a link-like rate).
+__global__ __launch_bounds__(256) void k_comm_test_copy(float4 *__restrict__ dst, const float4 *__restrict__ src, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // The three asynchronous collectives share everything but the RCCL call: they run on the communication stream after everything
 // queued so far on the compute stream, and leave an event in one of two FIFO queues (0: reductions -- all-reduce, reduce-scatter;
 // 1: all-gathers) that tomo_comm_wait_next / tomo_comm_wait_next_gather consume in issue order.
 enum { COLL_ALLREDUCE = 0, COLL_REDUCE_SCATTER = 1, COLL_ALLGATHER = 2 };
 static int comm_async(tomo_ctx *ctx, int kind, float *d_buf, int64_t n)
 {
+    TomoRange roctx_range(kind == COLL_ALLREDUCE ? "tomo_allreduce_sum_f32_async" : kind == COLL_REDUCE_SCATTER ? "tomo_reduce_scatter_sum_f32_async" : "tomo_allgather_f32_async");
     if (!ctx || n < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "bad args");
     if (!ctx->comm) return ctx->n_ranks == 1 ? TOMO_OK : tomo_fail(ctx, TOMO_ERR_STATE, "comm not initialised");
     if (!ctx->comm_stream) {
@@ -795,6 +853,22 @@ static int comm_async(tomo_ctx *ctx, int kind, float *d_buf, int64_t n)
         if (kind == COLL_ALLREDUCE) r = ncclAllReduce(d_buf, d_buf, (size_t)n, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream);
         else if (kind == COLL_REDUCE_SCATTER) r = ncclReduceScatter(d_buf, mine, (size_t)n, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream);
         else r = ncclAllGather(mine, d_buf, (size_t)n, ncclFloat32, ctx->comm, ctx->comm_stream);
+    }
+    if (ctx->comm_test_copy_eighths > 0 && n_all > 0) {
+        const size_t bytes = ((size_t)n_all * 4 * (size_t)ctx->comm_test_copy_eighths / 8) & ~(size_t)15;
+        if (bytes > ctx->comm_scratch_bytes) {
+            TOMO_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
+            if (ctx->d_comm_scratch) (void)hipFree(ctx->d_comm_scratch);
+            ctx->d_comm_scratch = nullptr;
+            ctx->comm_scratch_bytes = 0;
+            TOMO_HIP(ctx, hipMalloc(&ctx->d_comm_scratch, bytes));
+            ctx->comm_scratch_bytes = bytes;
+        }
+        if (bytes && ((uintptr_t)d_buf & 15) == 0 && ctx->comm_test_copy_wgs > 0)
+            hipLaunchKernelGGL(k_comm_test_copy, dim3(ctx->comm_test_copy_wgs), dim3(256), 0, ctx->comm_stream, (float4 *)ctx->d_comm_scratch, (const float4 *)d_buf,
+                               (int64_t)(bytes / 16));
+        else if (bytes)
+            TOMO_HIP(ctx, hipMemcpyAsync(ctx->d_comm_scratch, d_buf, bytes, hipMemcpyDeviceToDevice, ctx->comm_stream));
     }
     tomo_prof_end_on(ctx, ctx->comm_stream);
     if (r != ncclSuccess) return tomo_fail(ctx, TOMO_ERR_RCCL, std::string(names[kind]) + ": " + ncclGetErrorString(r));

@@ -294,6 +294,7 @@ static int forward_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
 
 extern "C" int tomo_forward(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_vol, float *d_proj)
 {
+    TomoRange roctx_range("tomo_forward");
     TOMO_NEED_GEOM(ctx);
     if (!h_poses || !d_vol || !d_proj || n_proj < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_forward: bad args");
     if (n_proj == 0) return TOMO_OK;
@@ -329,6 +330,7 @@ extern "C" int tomo_forward(tomo_ctx *ctx, const double *h_poses, int n_proj, co
 // final while the all-reduces of the other slabs are still in flight.  ADDS into d_proj (zero it before the first slab).
 extern "C" int tomo_forward_xslab(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_vol, float *d_proj, int xt0, int xt1)
 {
+    TomoRange roctx_range("tomo_forward_xslab");
     TOMO_NEED_GEOM(ctx);
     if (!h_poses || !d_vol || !d_proj || n_proj < 0 || xt0 < 0 || xt1 < xt0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_forward_xslab: bad args");
     bool done = false;
@@ -473,6 +475,7 @@ static int adjoint_tiles(tomo_ctx *ctx, const double *h_poses, int n_proj, const
 
 extern "C" int tomo_adjoint(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_proj, float *d_vol, int accumulate)
 {
+    TomoRange roctx_range("tomo_adjoint");
     TOMO_NEED_GEOM(ctx);
     if (!h_poses || !d_vol || !d_proj || n_proj < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_adjoint: bad args");
     const TomoGeomC &g = ctx->g;
@@ -503,6 +506,7 @@ extern "C" int tomo_adjoint_xslab_info(tomo_ctx *ctx, int *n_xtiles, int *tile_w
 
 extern "C" int tomo_adjoint_xslab(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_proj, float *d_vol, int xt0, int xt1)
 {
+    TomoRange roctx_range("tomo_adjoint_xslab");
     TOMO_NEED_GEOM(ctx);
     if (!h_poses || !d_vol || !d_proj || n_proj < 0 || xt0 < 0 || xt1 < xt0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_adjoint_xslab: bad args");
     bool done = false;
@@ -514,6 +518,7 @@ extern "C" int tomo_adjoint_xslab(tomo_ctx *ctx, const double *h_poses, int n_pr
 
 extern "C" int tomo_backproject_voxel(tomo_ctx *ctx, const double *h_poses, int n_proj, const float *d_det, float *d_vol)
 {
+    TomoRange roctx_range("tomo_backproject_voxel");
     TOMO_NEED_GEOM(ctx);
     if (!h_poses || !d_det || !d_vol || n_proj < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_backproject_voxel: bad args");
     const TomoGeomC &g = ctx->g;
@@ -543,6 +548,7 @@ extern "C" int tomo_backproject_voxel(tomo_ctx *ctx, const double *h_poses, int 
 
 extern "C" int tomo_proj_grad(tomo_ctx *ctx, const double *h_pose, const float *d_vol, float *d_proj, float *d_grad, int row_order)
 {
+    TomoRange roctx_range("tomo_proj_grad");
     TOMO_NEED_GEOM(ctx);
     if (!h_pose || !d_vol || !d_proj || !d_grad || (row_order != 0 && row_order != 1))
         return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_proj_grad: bad args");
@@ -585,6 +591,7 @@ extern "C" int tomo_cost_grad(tomo_ctx *ctx, const double *h_poses, int n, const
 extern "C" int tomo_cost_grad_rows(tomo_ctx *ctx, const double *h_poses, int n, const float *d_vol, const float *d_b,
                                    const int32_t *h_rows, int n_rows_total, double *h_cost, double *h_grad6, float *d_resid)
 {
+    TomoRange roctx_range("tomo_cost_grad_rows");
     TOMO_NEED_GEOM(ctx);
     if (!h_poses || !d_vol || !d_b || !h_cost || !h_grad6 || n < 0) return tomo_fail(ctx, TOMO_ERR_ARG, "tomo_cost_grad: bad args");
     if (h_rows)
