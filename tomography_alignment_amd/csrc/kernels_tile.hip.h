@@ -377,9 +377,10 @@ __global__ __launch_bounds__(NW * 64, TILE_MIN_WG) void k_tile(const AdjC *__res
                     const int64_t rb0 = c.fp0[0] + (int64_t)ix * c.fu[0] + (int64_t)jlo * c.fd[0] - org[0];
                     const int64_t rb1 = c.fp0[1] + (int64_t)ix * c.fu[1] + (int64_t)jlo * c.fd[1] - org[1];
                     const int64_t rb2 = c.fp0[2] + (int64_t)ix * c.fu[2] + (int64_t)jlo * c.fd[2] - org[2];
-                    // TOMO_ABLATE_TILE (timing experiments only, results are wrong by construction; profiles/round6_tilted_split.md): 1 = no sample
+                    // TOMO_ABLATE_TILE (timing experiments only, results are wrong by construction; profiles/round6_tilted_split.md): bit 0 = no sample
                     // loop (what is left is staging / zeroing, the per-(tile, projection) and per-row set-up, the row's global atomic or sinogram
-                    // read, and the flushes); 2 = adjoint without the flushes; 3 = both
+                    // read, and the flushes); bit 1 = adjoint without the flushes; bit 2 = forward without its atomics; bit 3 = forward with
+                    // plain stores instead of atomics
 #if defined(TOMO_ABLATE_TILE) && (TOMO_ABLATE_TILE & 1)
                     const int cnt = 0;
 #else
@@ -420,7 +421,13 @@ __global__ __launch_bounds__(NW * 64, TILE_MIN_WG) void k_tile(const AdjC *__res
                                 px = add64_vs(px, c.fd[0]); py = add64_vs(py, c.fd[1]); pz = add64_vs(pz, c.fd[2]);
                             }                                          // (two samples per trip, 8 reads in flight: measured no faster -- the loop is VALU-issue bound)
                             part = fmaf(partz, two_m32, part);
+#if defined(TOMO_ABLATE_TILE) && (TOMO_ABLATE_TILE & 4)
+                            if (lane_ok && part == 12345.678f) *pr = part;         // timing experiment: no atomic (the address is still formed)
+#elif defined(TOMO_ABLATE_TILE) && (TOMO_ABLATE_TILE & 8)
+                            if (lane_ok) *pr = part;                               // timing experiment: a plain store instead of the atomic
+#else
                             if (lane_ok) atomicAdd(pr, part);          // 64 consecutive floats per wave: the full-rate atomic shape
+#endif
                         } else {
                             const float ys = (lane_ok ? *pr : 0.f) * scale;
                             // straight-line body: a lane that does not own the sample adds integer 0 to a cell clamped into the image on
