@@ -187,16 +187,6 @@ __device__ __forceinline__ unsigned tile_cell_dword(unsigned cx, unsigned cy, un
     return r;
 }
 
-// the forward image's dword index of cell (cx, cy, cz): ((cx * ATY + cy) * 2) * ALZ + cz -- all powers of two, two shift-adds
-__device__ __forceinline__ unsigned tile_fwd_cell_dword(unsigned cx, unsigned cy, unsigned cz)
-{
-    static_assert(ATY == 16 && ALZ == 64, "shifts below");
-    unsigned t, r;
-    asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(t) : "v"(cx), "v"(cy));
-    asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(r) : "v"(t), "v"(cz));
-    return r;
-}
-
 #ifdef TOMO_TILE_CLAMP          // A/B switch (tools/gpu_r3c.sh): the round-2 form with the non-owners' cells clamped into the image
 #define TILE_CLAMP(v, hi) min((v), (unsigned)(hi))
 #define TILE_ZMASK(v) ((v) & 63u)
@@ -275,11 +265,7 @@ __global__ __launch_bounds__(NW * 64, TILE_MIN_WG) void k_tile(const AdjC *__res
                                                          float weight_bound, int tile_x0, const int *__restrict__ list, int nzt, int nty,
                                                          const int *__restrict__ zcum)
 {
-    // FWD (round 6): the image holds, per (x, y) column, a row A = v(x, y, .) and a row B = v(x, y + 1, .) - v(x, y, .) -- the y difference every
-    // sample used to form itself (one packed subtraction per x face per sample; same float32 rounding, so the sums are bit-identical): 17 x 16
-    // columns x 2 rows x 64 planes = 139 KB, one 16-wave work-group per CU as before.  ADJ: the (ATX+1)(ATY+1) x 64 fixed-point image.
-    constexpr int IMG_DWORDS = FWD ? (ALX * ATY * 2 * ALZ) : (ALX * ALY * ALZ);
-    __shared__ int acc[IMG_DWORDS + 4];             // + pad: a masked-out lane may read one dword past the last row (its value is discarded)
+    __shared__ int acc[ALX * ALY * ALZ + 4];        // + pad: a masked-out lane may read one dword past the last row (its value is discarded)
     const lds_cfloat *img3 = (const lds_cfloat *)acc;       // explicit LDS pointer: offsets made opaque below must still give ds_read
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -293,19 +279,13 @@ __global__ __launch_bounds__(NW * 64, TILE_MIN_WG) void k_tile(const AdjC *__res
     float scale = 1.f, inv_scale = 1.f;
     if (FWD) {
         bool any_nz = false;
-        for (int e = threadIdx.x; e < ALX * ATY * ALZ; e += NW * 64) {          // one (column, plane) per trip: its A and B entries
-            const int lz = e % ALZ, t2 = e / ALZ, ly = t2 % ATY, lx = t2 / ATY;
+        for (int e = threadIdx.x; e < ALX * ALY * ALZ; e += NW * 64) {
+            const int lz = e % ALZ, t2 = e / ALZ, ly = t2 % ALY, lx = t2 / ALY;
             const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
-            float v0 = 0.f, v1 = 0.f;
-            if (gx >= 0 && gx < g.nx && gz >= 0 && gz < g.nz) {
-                const float *col = vol + ((size_t)gx * g.ny) * g.nz + gz;
-                if (gy >= 0 && gy < g.ny) v0 = col[(size_t)gy * g.nz];
-                if (gy + 1 >= 0 && gy + 1 < g.ny) v1 = col[(size_t)(gy + 1) * g.nz];
-            }
-            const int o = ((lx * ATY + ly) * 2) * ALZ + lz;
-            ((float *)acc)[o] = v0;
-            ((float *)acc)[o + ALZ] = v1 - v0;                                   // the subtraction the sample loop no longer does
-            any_nz |= (v0 != 0.f) | (v1 != 0.f);
+            float v = 0.f;
+            if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny && gz >= 0 && gz < g.nz) v = vol[((size_t)gx * g.ny + gy) * g.nz + gz];
+            ((float *)acc)[e] = v;
+            any_nz |= (v != 0.f);
         }
         if (!__syncthreads_or(any_nz)) return;                   // an all-zero tile contributes nothing to any ray (none is left when the list is used)
     } else {
@@ -427,17 +407,16 @@ __global__ __launch_bounds__(NW * 64, TILE_MIN_WG) void k_tile(const AdjC *__res
                                 // 32 different banks.  (They used to read word 0: every such lane then hit bank 0 together with whichever
                                 // owner lane mapped there -- SQ_LDS_BANK_CONFLICT was 47 % of the kernel's LDS cycles, LDS 81 % busy.)
                                 const unsigned cx = TILE_CLAMP(lx, ATX - 1), cy = TILE_CLAMP(ly, ATY - 1), cz = TILE_ZMASK(lz);      // see tile_cell_dword
-                                const unsigned eb = tile_fwd_cell_dword(cx, cy, cz) << 2;               // byte offset of the cell's A entry
+                                const unsigned eb = tile_cell_dword(cx, cy, cz) << 2;                   // byte offset of the cell
                                 const f32x2 wxy = f32x2{(float)(unsigned)px, (float)(unsigned)py} * two_m32;          // one packed multiply for two of the three fractions
                                 const float wx = wxy.x, wy = wxy.y, fz32 = (float)(unsigned)pz;           // z fraction x 2^32 (scaled once per chunk)
-                                unsigned eb1 = eb + ATY * 2 * ALZ * 4;
-                                asm("" : "+v"(eb1));                      // one add for the x+1 face; a column's B row sits within ds_read2's offset range
+                                unsigned eb1 = eb + ALY * ALZ * 4;
+                                asm("" : "+v"(eb1));                      // one add for the x+1 face; its y+1 rows sit within ds_read2's offset range
                                 const lds_cfloat *q = (const lds_cfloat *)((const __attribute__((address_space(3))) char *)img3 + eb);
                                 const lds_cfloat *q1 = (const lds_cfloat *)((const __attribute__((address_space(3))) char *)img3 + eb1);
-                                const f32x2 a0 = {q[0], q[1]}, b0 = {q[ALZ], q[ALZ + 1]};                 // (z, z + 1) pairs of A and B = v(y + 1) - v(y), x face 0
-                                const f32x2 a1 = {q1[0], q1[1]}, b1 = {q1[ALZ], q1[ALZ + 1]};             // x face 1
-                                const f32x2 c0 = a0 + wy * b0, c1 = a1 + wy * b1;                         // y-lerped: one packed fma each (the difference is staged)
-                                const f32x2 e = c0 + wx * (c1 - c0);
+                                const f32x2 p00 = {q[0], q[1]}, p01 = {q[ALZ], q[ALZ + 1]};
+                                const f32x2 p10 = {q1[0], q1[1]}, p11 = {q1[ALZ], q1[ALZ + 1]};
+                                const f32x2 e = bilerp_pairs(p00, p01, p10, p11, wx, wy);
                                 zlerp_acc_lanes(part, partz, e.x, e.y, fz32, own);
                                 px = add64_vs(px, c.fd[0]); py = add64_vs(py, c.fd[1]); pz = add64_vs(pz, c.fd[2]);
                             }                                          // (two samples per trip, 8 reads in flight: measured no faster -- the loop is VALU-issue bound)
