@@ -227,6 +227,34 @@ def test_fused_cost_gradient_is_deterministic(PM, shape, ndet):
     be.ctx.set_option("grad_variant", 4)
 
 
+def test_fused_cost_gradient_batches_larger_than_the_partial_buffer(PM):
+    """tomo_cost_grad_rows keeps the work-groups' partial sums of at most 512 MB worth of poses at a time (csrc/tomo_project.hip:
+    TOMO_RED_PART_BYTES) and sends a larger batch through in several launches.  A 1024 x 1024 detector has 4096 work-groups per pose =
+    224 KB of partials: 2500 poses cross the limit (2340).  The call must give, bit for bit, what the same poses give in small batches --
+    in both tilt groups, with row indices into a two-row table (the measured rows stay tiny; the volume is a thin slab, most rays miss)."""
+    from tomography_alignment_amd import _lib
+    rng = np.random.default_rng(31)
+    shape, ndet, n = (48, 24, 40), (1024, 1024), 2500
+    geo, _ = geo_pair(2, None, ndet=ndet, shape=shape)
+    be = PM(geo).backend
+    x = rng.uniform(0.1, 1.0, shape).astype(np.float32)
+    phi = rng.uniform(0.0, np.pi, n)
+    alpha, beta = np.deg2rad(rng.uniform(-2, 2, n)), np.deg2rad(rng.uniform(-2, 2, n))
+    alpha[::3] = beta[::3] = 0.0                                   # a third of the poses in the untilted group
+    xyz = rng.uniform(-4, 4, (n, 3))
+    poses = _lib.poses_array(phi, alpha, beta, xyz, np.zeros(3))
+    vol = be.upload(x)
+    b = be.upload(rng.standard_normal(2 * be.n_det).astype(np.float32))
+    rows = (np.arange(n) % 2).astype(np.int32)
+    c_all, g_all = be.cost_grad(poses, vol, b, rows=rows)
+    assert np.all(np.isfinite(c_all)) and np.all(c_all > 0)
+    for lo in (0, 1200, 2300, 2490):                               # windows on both sides of the internal cut, and the tail
+        hi = min(n, lo + 10)
+        c, g = be.cost_grad(np.ascontiguousarray(poses[lo:hi]), vol, b, rows=rows[lo:hi])
+        assert np.array_equal(c, c_all[lo:hi]) and np.array_equal(g, g_all[lo:hi]), lo
+    be.ctx.check(be.lib.tomo_release_workspace(be.ctx.handle))      # hands the 512 MB of partials back
+
+
 @pytest.mark.parametrize("shape,ndet,step,n_proj", [((20, 24, 70), (20, 70), 1.0, 3),     # ragged, nz > 64, not multiple of 64
                                                     ((16, 16, 5), (16, 5), 1.0, 2),       # nz << 64
                                                     ((24, 24, 24), (30, 40), 0.7, 2),     # detector larger than volume, odd step
