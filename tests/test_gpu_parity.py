@@ -930,6 +930,22 @@ def test_vox_wt_grad_twin_vs_reference_golden():
         img, grad = vox_wt_grad.bilinear_vox_interp(geo.n_vox, fx, fz, ax, az, np.asfortranarray(x.ravel()), 16, 16, np.asfortranarray(der))
         assert np.array_equal(img.ravel(), g8["img%d" % i]) and rel_max(grad.reshape(6, -1), g8["grad%d" % i]) < 1e-6
         print("vox_wt_grad twin, G8 pose %d: image identical, gradient rel-max %.1e" % (i, rel_max(grad.reshape(6, -1), g8["grad%d" % i])))
+    # a size at which the device path matters (262 144 voxels -> a million (pixel, entry) pairs to sort; several hundred voxels per pixel, so the ORDER of
+    # the single-precision additions decides the last bits): against the oracle's serial restatement, which G13 pins to the f2py module bit for bit
+    from oracle import oracle as orc
+    rng = np.random.default_rng(13)
+    nv, ndx, ndz = 64 ** 3, 70, 50
+    fxr = rng.integers(-3, ndx + 2, nv).astype(np.int32)
+    fzr = rng.integers(-3, ndz + 2, nv).astype(np.int32)
+    axr, azr = rng.uniform(0, 1, nv).astype(np.float32), rng.uniform(0, 1, nv).astype(np.float32)
+    rr = rng.uniform(-1, 1, nv).astype(np.float32)
+    derr = rng.standard_normal((6, 3, nv)).astype(np.float32)
+    dat, det, wts, k = vox_wt_grad.bilinear_sparse(nv, fxr, fzr, axr, azr, ndx, ndz)
+    o_dat, o_det, o_wts, o_k = orc.bilinear_sparse(nv, fxr, fzr, axr, azr, ndx, ndz)
+    assert k == o_k and np.array_equal(dat, o_dat) and np.array_equal(det, o_det) and np.array_equal(wts, o_wts)
+    img, grad = vox_wt_grad.bilinear_vox_interp(nv, fxr, fzr, axr, azr, rr, ndx, ndz, derr)
+    o_img, o_grad = orc.bilinear_vox_interp(nv, fxr, fzr, axr, azr, rr, ndx, ndz, derr)
+    assert np.array_equal(img, o_img) and np.array_equal(grad, o_grad)
     # edge cases
     z = np.zeros(0, np.int32)
     dat, det, wts, k = vox_wt_grad.bilinear_sparse(0, z, z, z.astype(np.float32), z.astype(np.float32), 3, 2)
