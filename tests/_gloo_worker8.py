@@ -95,6 +95,31 @@ def main(out_path):
     r_r, r_s = ref.align(**tight), shd.align(**tight)
     out["st_align_x"] = float(np.max(np.abs(r_s["x"] - r_r["x"])))
     out["st_align_nfev"] = int(np.max(np.abs(r_s["nfev"] - r_r["nfev"])))
+    # ---- more ranks than angles: 6 angles on 8 ranks -- ranks 6 and 7 own NO projection (np.array_split gives them empty blocks), yet must issue every
+    # collective of every iteration (their partial volumes are zero) and end with the same reconstruction; SIRT pipelined, CGLS, and an alignment pass
+    # in which two ranks have nothing to align (align_projections_sharded's empty-block branch)
+    n6 = 6
+    phi6 = np.linspace(0.1, 3.0, n6)
+    geo6 = Geometry(n6, np.array(shape), np.ones(3), np.array(ndet), np.ones(2))
+    og6 = orc.Geo(n6, np.array(shape), np.ones(3), np.array(ndet), np.ones(2))
+    b6 = orc.forward(og6, x, phi=phi6).astype(np.float32).reshape(n6, -1)
+    ang6 = np.array([phi6, 0 * phi6, 0 * phi6]).T
+    mine6 = np.array_split(np.arange(n6), comm.size)[comm.rank]
+    sh6 = sirt_mpi.SIRT._shard_geometry(geo6, mine6)
+    c7 = counts(comm)
+    s6 = sirt_mpi.SIRT(comm, geo6, b6.copy(), ang6, np.zeros((n6, 3)), options={"_backend": OracleBackend(sh6), "ground_truth": x})
+    rec6, err6 = s6.run_main_iteration(niter=2, positivity=True)
+    cg6 = cgls_mpi.CGLS(comm, geo6, b6.copy(), ang6, np.zeros((n6, 3)), options={"_backend": OracleBackend(sh6)})
+    crec6, cerr6 = cg6.run_main_iteration(niter=2)
+    c8 = counts(comm)
+    out.update(few_sirt_rec=rec6, few_sirt_err=err6, few_cgls_rec=crec6, few_cgls_err=cerr6, few_counts=c8 - c7, few_my_n=np.array(mine6.size),
+               few_pipelined=bool(s6._iter_pipelined))
+    out["few_empty_ranks"] = np.array(int(round(comm.allreduce_scalar(1.0 if mine6.size == 0 else 0.0))))
+    from tomography_alignment_amd import alignment
+    phia = phie[:n6]
+    resa = alignment.align_projections_sharded(comm, OracleBackend(Geometry(n6, np.array([Na] * 3), np.ones(3), np.array([Na, Na]), np.ones(2))), xa, be_[:n6], phia,
+                                               letters="xzab", bounds=((-3., 3.), (-3., 3.), (-0.02, 0.02), (-0.02, 0.02)), **tight)
+    out.update(few_align_x=resa["x"], few_align_nfev=resa["nfev"])
     # ---- rank-uniform bookkeeping: every rank issued the same number of every kind of collective (a mismatch would have hung gloo; this
     # also shows it in the record), taken over the whole program
     total = counts(comm)

@@ -164,6 +164,12 @@ def test_world_8_sirt_cgls_and_outer_loop(tmp_path):
     assert int(eight["e_uploaded_rows"]) == 2 + 16 and int(one["e_uploaded_rows"]) == 10 + 16
     assert abs(eight["e_rmse"][0] / one["e_rmse"][0] - 1) < 1e-5 and np.max(np.abs(eight["e_xyz"] - one["e_xyz"])) < 0.2
     assert eight["e_shift_err"][-1] < 0.7 * np.abs(eight["e_true"][:, :2]).mean()
+    # more ranks than angles (6 on 8): two ranks own nothing, issue every collective, and everybody ends with the one-rank answer
+    assert int(eight["few_empty_ranks"]) == 2 and int(one["few_empty_ranks"]) == 0 and bool(eight["few_pipelined"])
+    assert rel_max(eight["few_sirt_rec"], one["few_sirt_rec"]) < 1e-5 and np.allclose(eight["few_sirt_err"], one["few_sirt_err"], rtol=1e-5)
+    assert rel_max(eight["few_cgls_rec"], one["few_cgls_rec"]) < 1e-5 and np.allclose(eight["few_cgls_err"], one["few_cgls_err"], rtol=1e-5)
+    assert np.allclose(eight["few_align_x"], one["few_align_x"], atol=1e-12) and np.array_equal(eight["few_align_nfev"], one["few_align_nfev"])
+    assert np.abs(one["few_align_x"]).max() > 0.1
 
 
 def test_angle_split_is_the_reference_split():
