@@ -238,6 +238,22 @@ def main(out_path):
             out["%s_cgls_%s_counts" % (tag, mode)] = np.array([getattr(comm, "n_rs", 0) - r0, getattr(comm, "n_ag", 0) - a0, comm.n_slab_allreduce - s0,
                                                                int(getattr(c, "_iter_pipelined", False))])
     align_rigid_stages(ctx, comm, out)
+    # ---- a rank without angles on the REAL backend: one projection on this world (at world 2 rank 1 owns nothing: zero-row tables, no projector
+    # call, every collective issued), plain and pipelined; the one-rank answer must come out
+    x1 = np.zeros((32, 32, 32), np.float32)
+    x1[8:24, 10:22, 6:26] = rng.uniform(0.2, 1.0, (16, 12, 20)).astype(np.float32)
+    geo1 = Geometry(1, np.array([32] * 3), np.ones(3), np.array([32, 32]), np.ones(2))
+    ang1 = np.array([[0.7, 0.0, 0.0]])
+    b1 = HipBackend(geo1, ctx=ctx)
+    p1 = b1.forward(_lib.poses_array([0.7], [0.0], [0.0], np.zeros((1, 3)), np.zeros(3)), b1.upload(x1), b1.empty(1024)).download().reshape(1, -1)
+    mine1 = np.array_split(np.arange(1), comm.size)[comm.rank]
+    for mode in ("pipelined", "plain"):
+        comm.force_pipeline = mode == "pipelined"
+        s1 = sirt_mpi.SIRT(comm, geo1, p1.copy(), ang1, np.zeros((1, 3)), options={"_backend": HipBackend(sirt_mpi.SIRT._shard_geometry(geo1, mine1), ctx=ctx)})
+        r1, e1 = s1.run_main_iteration(niter=3, positivity=True)
+        out["one_angle_%s_rec" % mode], out["one_angle_%s_err" % mode] = r1, e1
+    comm.force_pipeline = False
+    out["one_angle_empty_ranks"] = np.array(int(round(comm.allreduce_scalar(1.0 if mine1.size == 0 else 0.0))))
     if comm.rank == 0:
         np.savez(out_path, **out)
     dist.barrier()

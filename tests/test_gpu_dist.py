@@ -82,3 +82,9 @@ def test_sharded_sirt_world_2_on_the_gpu(tmp_path):
         assert bool(w["e_pipelined"]) and float(w["st_pose_moved"]) > 0.5 and float(w["e_spread"]) == 0.0
         assert abs(w["e_rmse"][0] / one["e_rmse"][0] - 1) < 1e-5
         assert w["e_shift_err"][-1] < w["e_shift_err"][0] < 0.7 * float(w["e_injected"])
+    # one projection on two ranks: rank 1 owns no angle (zero-row tables on the real backend, no projector call, every collective issued)
+    assert int(two["one_angle_empty_ranks"]) == 1 and int(one["one_angle_empty_ranks"]) == 0
+    for mode in ("pipelined", "plain"):
+        assert rel_max(two["one_angle_%s_rec" % mode], one["one_angle_plain_rec"]) < 1e-5, mode
+        assert np.allclose(two["one_angle_%s_err" % mode], one["one_angle_plain_err"], rtol=1e-5), mode
+    assert one["one_angle_plain_rec"].max() > 0
