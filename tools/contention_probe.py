@@ -5,7 +5,7 @@ beside the kernels.  On one rank RCCL moves nothing; the opt
 copy 7/8 of the slab it touches on the communication stream -- per step 2 x 7/8 x 4.3 GB, the bytes a ring reduce-scatter + all-gather read
 and write in one GPU's HBM at P = 8 -- either as a hipMemcpyAsync burst or through a copy kernel of w work-groups (RCCL-like: few work-groups
 that hold CUs and stream at a limited rate; w sets the rate).
-    python tools/contention_probe.py [N] [angles] [steps]          -> a markdown table on stdout (profiles/round6_contention_probe.md)"""
+    python tools/contention_probe.py [N] [angles] [steps] [slabs] [quick]    -> a markdown table on stdout (profiles/round6_contention_probe.md)"""
 import os
 import sys
 import time
@@ -25,6 +25,8 @@ from tomography_alignment_amd.utilities.generate_phantom import SHEPP_LOGAN  # n
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n_proj = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+slabs = int(sys.argv[4]) if len(sys.argv) > 4 else None          # x slabs of the pipelined iteration (default: the solver's own, 8)
+quick = len(sys.argv) > 5 and sys.argv[5] == "quick"             # only: none / 32 / 64 work-groups
 NAMES = ("k_fwd_tile_flat", "k_adj_gather_flat", "k_fwd_live", "k_sino_zflags", "k_update", "k_residual_scale", "reduce_scatter_f32", "allgather_f32", "comm_join_wait")
 
 ctx = _lib.Context(0)
@@ -36,6 +38,8 @@ phi = np.linspace(0.0, np.pi, 8 * n_proj)[3 * n_proj:4 * n_proj]
 be = HipBackend(geo, ctx=ctx)
 d_true = be.phantom(be.empty(N ** 3), (N, N, N), SHEPP_LOGAN)
 d_b = be.forward(_lib.poses_array(phi, 0 * phi, 0 * phi, np.zeros((n_proj, 3)), np.zeros(3)), d_true, be.empty(n_proj * N * N))
+if slabs is not None:
+    sirt_mpi.SIRT.n_pipeline_slabs = slabs
 solver = sirt_mpi.SIRT(comm, geo, d_b, np.array([phi, 0 * phi, 0 * phi]).T, np.zeros((n_proj, 3)), {"_backend": be})
 solver.iterate_device(niter=2)
 ctx.sync()
@@ -44,6 +48,8 @@ rows = []
 for label, k8, wgs in (("no synthetic traffic (one-rank collectives move nothing)", 0, 0), ("hipMemcpyAsync burst", 7, 0), ("copy kernel, 8 work-groups", 7, 8),
                        ("copy kernel, 16 work-groups", 7, 16), ("copy kernel, 32 work-groups", 7, 32), ("copy kernel, 64 work-groups", 7, 64),
                        ("copy kernel, 256 work-groups", 7, 256), ("no synthetic traffic, again", 0, 0)):
+    if quick and wgs not in (0, 32, 64) or (quick and label.startswith(("hipMemcpy", "no synthetic traffic, again"))):
+        continue
     ctx.set_option("comm_test_copy_eighths", k8)
     ctx.set_option("comm_test_copy_wgs", wgs)
     solver.iterate_device(niter=1)
