@@ -972,6 +972,26 @@ def test_vox_wt_grad_twin_vs_reference_golden():
     assert img.shape == (1, 1) and img[0, 0] == acc
 
 
+def test_gather_back_projection_of_untilted_poses_is_bit_reproducible(PM):
+    """INTEGRATION.md "reproducibility": the gather-form back-projection of untilted poses (k_adj_gather_flat: every voxel column sums its own
+    projections, no atomics) returns the same bits on every call; the forward projector's float32 atomics do not promise that (and are not asked to)."""
+    from tomography_alignment_amd import _lib
+    rng = np.random.default_rng(41)
+    shape, ndet, n = (96, 80, 200), (100, 210), 24
+    geo, _ = geo_pair(n, None, ndet=ndet, shape=shape)
+    be = PM(geo).backend
+    phi = np.linspace(0.0, np.pi, n)
+    xyz = np.zeros((n, 3))
+    xyz[:, 0], xyz[:, 2] = rng.uniform(-2, 2, n), rng.uniform(-2, 2, n)
+    poses = _lib.poses_array(phi, np.zeros(n), np.zeros(n), xyz, np.zeros(3))
+    y = be.upload(rng.standard_normal(n * ndet[0] * ndet[1]).astype(np.float32))
+    first = be.adjoint(poses, y, be.empty(int(np.prod(shape)))).download()
+    assert np.abs(first).max() > 0
+    for _ in range(3):
+        again = be.adjoint(poses, y, be.empty(int(np.prod(shape)))).download()
+        assert np.array_equal(again, first)
+
+
 def test_empty_inputs(PM, shepp32):
     """Zero projections (a rank of a sharded run that owns no angle: np.array_split hands out empty blocks when there are more ranks than angles,
     recon/sirt_mpi.py:40) and zero-sized buffers: every entry point returns without touching anything it should not -- forward writes nothing, the
