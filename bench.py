@@ -490,6 +490,9 @@ def compact_roofline(r):
         c["counters"] = None                                     # says: algorithmic-HBM fallback, no committed PMC passes for this workload / these sources
     if r.get("stale_counters_refused"):
         c["stale_counters_refused"] = len(r["stale_counters_refused"])
+    if c.get("hbm_algorithmic_frac") is not None and c["hbm_algorithmic_frac"] > 1.0 and c.get("bound") != "hbm":
+        c["note"] = ("bound / frac = the busiest MEASURED unit (PMC counters / live time); hbm_algorithmic_frac = SURVEY 8d bytes (volume re-read per angle) "
+                     "/ time / 8 TB/s, above 1 because a block is staged once for all angles; hbm_counter_frac = what the HBM carried")
     return c
 
 
